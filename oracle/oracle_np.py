@@ -1,0 +1,250 @@
+"""CPU oracle (numpy) for the fake-quantization hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a plain restatement of the reference's algorithm
+(antspy/quantized_distillation, quantization/quant_functions.py and
+quantization/help_functions.py) in numpy fp32 arithmetic, one separately rounded IEEE operation
+per reference tensor op, in the reference's op order.  It exists to CHECK the HIP path; nothing
+in the product (`quantized_distillation_amd/`, `quantization/`) imports it.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may use it.
+
+Parity pin: every function here is checked in tests/test_oracle_golden.py against the vectors in
+tests/golden/*.npz, which were produced by running the unmodified reference
+(tests/golden/gen_golden.py).  The reference has no tests or golden vectors of its own
+(SURVEY.md section 4), so "the reference executed here" is the pin.
+
+All `ref:` citations are relative to /root/reference/.
+"""
+import numpy as np
+
+F32 = np.float32
+TOL_DIFF_ZERO = 1e-10          # ref: quantization/quant_functions.py:40
+
+
+# ----------------------------------------------------------------------------- bucket geometry
+def bucket_geometry(n, bucket):
+    """(num_buckets, row_length, padded_length) of the bucket view of an n-element tensor.
+
+    ref: quantization/help_functions.py:67-94 -- n < bucket: one short row of n elements;
+    n % bucket == 0: n/bucket full rows; otherwise one extra row padded with copies of the
+    last element.  bucket None: a single row holding the whole tensor (1-D in the reference).
+    """
+    if bucket is None:
+        return 1, n, n
+    mult, rest = divmod(n, bucket)
+    if mult == 0:
+        return 1, n, n
+    if rest == 0:
+        return mult, bucket, n
+    return mult + 1, bucket, (mult + 1) * bucket
+
+
+def bucketize(v, bucket):
+    """ref: help_functions.py:67-94 (fill_values='last').  v: 1-D fp32.  Returns 2-D rows
+    (or the 1-D vector when bucket is None, as quant_functions.py:79-80 does)."""
+    n = v.size
+    if bucket is None:
+        return v
+    nb, row, padded = bucket_geometry(n, bucket)
+    if padded != n:
+        v = np.concatenate([v, np.full(padded - n, v[-1], dtype=F32)])
+    return v.reshape(nb, row)
+
+
+# ----------------------------------------------------------------------------- scaling
+def scale_down(x, bucket=None, max_element=False, subtract_mean=False, mean=None):
+    """Linear scaling to [0,1].  ref: quant_functions.py:56-107,129.
+
+    Returns dict(u, alpha, beta, imin, imax, mean, n, shape).  `u` has the bucket layout
+    (nb, row) -- or (n,) when bucket is None -- INCLUDING the padding of a ragged last bucket.
+    `mean` overrides the fp32 mean (torch's summation order is not reproducible in numpy;
+    tests pass the value the implementation under test reports).
+    """
+    x = np.asarray(x, dtype=F32)
+    shape = x.shape
+    v = x.reshape(-1).copy()
+    n = v.size
+    if subtract_mean:                                             # :66-68
+        m = F32(np.mean(v, dtype=np.float64)) if mean is None else F32(mean)
+        v = (v - m).astype(F32)
+    else:
+        m = F32(0.0)                                              # :70
+    if max_element is not False:                                  # :72-74
+        me = F32(max_element)
+        v = np.where(v > me, me, v)
+        v = np.where(v < -me, -me, v).astype(F32)
+    t = bucketize(v, bucket)                                      # :78-81
+    axis = 0 if bucket is None else 1
+    mn = t.min(axis=axis, keepdims=True)                          # :85-90
+    mx = t.max(axis=axis, keepdims=True)
+    imin = t.argmin(axis=axis).reshape(mn.shape).astype(np.int64)  # first occurrence, like torch
+    imax = t.argmax(axis=axis).reshape(mx.shape).astype(np.int64)
+    alpha = (mx - mn).astype(F32)                                 # :91
+    beta = mn.astype(F32)                                         # :92
+    alpha = np.where(alpha < F32(TOL_DIFF_ZERO), F32(1.0), alpha).astype(F32)   # :95-99
+    u = ((t - beta).astype(F32) / alpha).astype(F32)              # :106-107 (sub, then true div)
+    return dict(u=u, alpha=alpha, beta=beta, imin=imin, imax=imax, mean=m, n=n, shape=shape)
+
+
+def inv_scale_down(u, alpha, beta, mean, n, shape):
+    """ref: quant_functions.py:131-152: mul, add (two roundings), add mean, strip padding."""
+    y = (u * alpha).astype(F32)                                   # :142
+    y = (y + beta).astype(F32)                                    # :143
+    y = (y + F32(mean)).astype(F32)                               # :148
+    return y.reshape(-1)[:n].reshape(shape)                       # :149-150
+
+
+# ----------------------------------------------------------------------------- uniform
+def uniform_quantize(x, s, bucket=None, max_element=False, subtract_mean=False, mean=None):
+    """Deterministic k-level quantize-dequantize.  ref: quant_functions.py:155-194 (:189-191).
+
+    Returns dict(q, lev, alpha, beta, imin, imax, mean, u).  `lev` = rint(u*(s-1)) as int32 in
+    the bucket layout (padding included) -- the integer path that must match bit-exactly.
+    """
+    sd = scale_down(x, bucket, max_element, subtract_mean, mean)
+    sm1 = F32(s - 1)                                              # :172
+    t = (sd['u'] * sm1).astype(F32)                               # :189
+    r = np.rint(t).astype(F32)                                    # :190 round half to even
+    w = (r / sm1).astype(F32)                                     # :191
+    q = inv_scale_down(w, sd['alpha'], sd['beta'], sd['mean'], sd['n'], sd['shape'])   # :193
+    out = dict(sd)
+    out.update(q=q, lev=r.astype(np.int32))
+    return out
+
+
+def uniform_quantize_stochastic(x, s, rand, bucket=None, max_element=False, subtract_mean=False, mean=None):
+    """Stochastic-rounding variant given the uniform [0,1) draws `rand` (bucket layout).
+    ref: quant_functions.py:174-187."""
+    sd = scale_down(x, bucket, max_element, subtract_mean, mean)
+    sm1 = F32(s - 1)
+    prob = (sm1 * sd['u']).astype(F32)                            # :179
+    t = (sd['u'] * sm1).astype(F32)                               # :180
+    fl = np.floor(t).astype(F32)                                  # :181
+    prob = (prob - fl).astype(F32)                                # :182
+    w = (fl / sm1).astype(F32)                                    # :183
+    inc = ((np.asarray(rand, dtype=F32).reshape(w.shape) <= prob).astype(F32) * F32(1.0) / sm1).astype(F32)
+    w = (w + inc).astype(F32)                                     # :187
+    q = inv_scale_down(w, sd['alpha'], sd['beta'], sd['mean'], sd['n'], sd['shape'])
+    out = dict(sd)
+    out.update(q=q)
+    return out
+
+
+# ----------------------------------------------------------------------------- non-uniform
+def assign_distance(u, pts):
+    """Nearest sorted point, ties to the UPPER point.  ref: quant_functions.py:267-273."""
+    pts = np.asarray(pts, dtype=F32)
+    flat = u.reshape(-1)
+    i = np.searchsorted(pts, flat, side='left').clip(max=pts.size - 1)            # :267-268
+    lower = (i > 0) & (np.fabs(flat - pts[np.maximum(i - 1, 0)]) < np.fabs(flat - pts[i]))   # :269-272
+    return (i - lower).astype(np.int64).reshape(u.shape)                           # :273
+
+
+def midpoints(pts):
+    """ref: quant_functions.py:533 -- k[:-1] + diff(k)/2 in fp32."""
+    pts = np.asarray(pts, dtype=F32)
+    return (pts[:-1] + (np.diff(pts) / F32(2.0)).astype(F32)).astype(F32)
+
+
+def assign_midpoint(u, pts):
+    """Index = #{midpoints <= u}: what SearchSorted.query computes through the sorted copy.
+    ref: quant_functions.py:531-573 (searchsorted-left of the midpoints INTO the sorted tensor,
+    :534, means element e gets index j iff exactly j midpoints are <= e)."""
+    m = midpoints(pts)
+    return np.searchsorted(m, u.reshape(-1), side='right').astype(np.int64).reshape(u.shape)
+
+
+def nonuniform_quantize(x, pts, bucket=None, mode='distance', max_element=False, subtract_mean=False, mean=None):
+    """ref: quant_functions.py:196-290.  mode 'distance' = plain path (:267-273), 'midpoint' =
+    pre-processed path (:275 -> SearchSorted.query).  Returns dict(q, idx, alpha, beta, ...);
+    idx is int64 with the ORIGINAL shape (:288-289)."""
+    pts = np.asarray(pts, dtype=F32)
+    sd = scale_down(x, bucket, max_element, subtract_mean, mean)
+    idx_full = assign_distance(sd['u'], pts) if mode == 'distance' else assign_midpoint(sd['u'], pts)
+    w = pts[idx_full]                                                               # :278
+    q = inv_scale_down(w, sd['alpha'], sd['beta'], sd['mean'], sd['n'], sd['shape'])   # :286-287
+    idx = idx_full.reshape(-1)[:sd['n']].reshape(sd['shape'])
+    out = dict(sd)
+    out.update(q=q, idx=idx)
+    return out
+
+
+def point_grad(g, idx, alpha, bucket, k, dtype=np.float64):
+    """gradPoint[j] = sum_{i: idx_i == j} g_i * alpha_bucket(i).  ref: quant_functions.py:493-503.
+    The product g*alpha is one fp32 multiply (:495); the per-bin sum is accumulated in `dtype`
+    (float64 by default = the exact-ish value both torch's fp32 sum and the HIP reduction are
+    compared against, with a tolerance relative to sum|g*alpha|)."""
+    g = np.asarray(g, dtype=F32).reshape(-1)
+    idx = np.asarray(idx).reshape(-1)
+    n = g.size
+    if bucket is None:
+        a = np.broadcast_to(np.asarray(alpha, dtype=F32).reshape(-1)[:1], (n,))
+    else:
+        nb, row, _ = bucket_geometry(n, bucket)
+        a = np.repeat(np.asarray(alpha, dtype=F32).reshape(-1), row)[:n]
+    mg = (g * a).astype(F32)
+    out = np.zeros(k, dtype=dtype)
+    np.add.at(out, idx, mg.astype(dtype))
+    absum = np.zeros(k, dtype=np.float64)
+    np.add.at(absum, idx, np.abs(mg).astype(np.float64))
+    return out, absum
+
+
+# ----------------------------------------------------------------------------- STE variants
+def ste_complicated_backward(x, g, s, bucket, tie_mode='reference'):
+    """'complicated' straight-through backward.  ref: quant_functions.py:319-406 with the two
+    shape fixes of SURVEY.md 8c (the shipped code raises for > 1 bucket).
+
+    Closed form: per bucket S_b = sum_i g_i*(qs_i - u_i) over the real (non
+    padded) elements, out = g, out[jmax_b] += S_b, out[jmin_b] -= S_b.
+    Reference-faithful details reproduced here:
+      * :350 re-runs scale_down on the QUANTIZED tensor, so alpha/beta/jmin/jmax are those of q
+        (jmax = first element at the top level; tie_mode 'reference'), and qs = (q-beta_q)/alpha_q;
+      * u_i = (x_i - beta_q)/alpha_q (:400) uses the same re-derived alpha/beta.
+      * the sum is what torch.mm of the sparse +-1 matrix does: fp32 accumulate; we accumulate in
+        float64 and compare with tolerance.
+    tie_mode 'true_arg' uses argmax/argmin of x instead.
+    """
+    x = np.asarray(x, dtype=F32)
+    g = np.asarray(g, dtype=F32)
+    shape = x.shape
+    n = x.size
+    uq = uniform_quantize(x, s, bucket)
+    q = uq['q']
+    sdq = scale_down(q, bucket)                       # :350 (overwrites alpha, beta, idx)
+    nb, row, padded = bucket_geometry(n, bucket)
+    qs = sdq['u'].reshape(-1)[:n]
+    alpha = np.repeat(sdq['alpha'].reshape(-1), row)[:n]
+    beta = np.repeat(sdq['beta'].reshape(-1), row)[:n]
+    u = ((x.reshape(-1) - beta).astype(F32) / alpha).astype(F32)       # :400 (tensor-beta)/alpha
+    term = (g.reshape(-1) * (qs - u).astype(F32)).astype(F32)
+    if tie_mode == 'reference':
+        jmax, jmin = sdq['imax'].reshape(-1), sdq['imin'].reshape(-1)
+    else:
+        sdx = scale_down(x, bucket)
+        jmax, jmin = sdx['imax'].reshape(-1), sdx['imin'].reshape(-1)
+    out = g.reshape(-1).astype(np.float64).copy()
+    for b in range(nb):
+        lo, hi = b * row, min((b + 1) * row, n)
+        sb = term[lo:hi].astype(np.float64).sum()
+        # the reference adds grad_alpha^T . term: column jmax gets +sum over rows i of the bucket
+        # whose (expanded, truncated to n) idx points at it
+        out[lo + jmax[b]] += sb
+        out[lo + jmin[b]] -= sb
+    return out.astype(F32).reshape(shape)
+
+
+def truncated_ste_mask(w, grad):
+    """'truncated' STE: grad[|w| > 1] = 0.  ref: cnn_models/conv_forward_model.py:263-264."""
+    w = np.asarray(w, dtype=F32)
+    out = np.asarray(grad, dtype=F32).copy()
+    out[np.abs(w) > F32(1.0)] = F32(0.0)
+    return out
+
+
+# ----------------------------------------------------------------------------- setup helpers
+def init_points_percentile(x, bucket, k, max_element=False, subtract_mean=False):
+    """ref: help_functions.py:140-154 -- np.percentile (linear interpolation, float64) of the
+    scaled tensor without padding, cast back to fp32."""
+    sd = scale_down(x, bucket, max_element, subtract_mean)
+    flat = sd['u'].reshape(-1)[:sd['n']]
+    return np.percentile(flat, np.linspace(0, 100, num=k)).astype(F32)

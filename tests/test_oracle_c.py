@@ -1,0 +1,87 @@
+"""The C oracle (oracle/qd_oracle.c) must agree bit-for-bit with the numpy oracle, with the
+golden vectors produced by the reference, and with the reference's full-size checksums."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+from oracle import oracle_np as onp
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _build():
+    oc.build()
+
+
+def test_c_uniform_vs_golden(golden_uniform):
+    G = golden_uniform
+    for i, c in enumerate(G.meta):
+        x = G.arr('u', i, 'x')
+        r = oc.uniform_quantize(x, c['s'], c['bucket'], c['max_element'], c['subtract_mean'],
+                                mean=c['mean'] if c['subtract_mean'] else None)
+        tag = 'case %d %r' % (i, c)
+        n = x.size
+        assert np.array_equal(r['q'], G.arr('u', i, 'q')), tag
+        assert np.array_equal(r['alpha'], G.arr('u', i, 'alpha').reshape(-1)), tag
+        assert np.array_equal(r['beta'], G.arr('u', i, 'beta').reshape(-1)), tag
+        assert np.array_equal(r['imin'], G.arr('u', i, 'imin').reshape(-1)), tag
+        assert np.array_equal(r['imax'], G.arr('u', i, 'imax').reshape(-1)), tag
+        assert np.array_equal(r['lev'], G.arr('u', i, 'lev').reshape(-1)[:n]), tag
+        sd = oc.scale_down(x, c['bucket'], c['max_element'], c['subtract_mean'],
+                           mean=c['mean'] if c['subtract_mean'] else None)
+        assert np.array_equal(sd['u'], G.arr('u', i, 'u').reshape(-1)[:n]), tag
+
+
+def test_c_nonuniform_vs_golden(golden_nonuniform):
+    G = golden_nonuniform
+    for i, c in enumerate(G.meta):
+        x, pts = G.arr('n', i, 'x'), G.arr('n', i, 'pts')
+        r = oc.nonuniform_quantize(x, pts, c['bucket'], 'distance')
+        assert np.array_equal(r['idx'], G.arr('n', i, 'idx')) and np.array_equal(r['q'], G.arr('n', i, 'q')), (i, c)
+        r = oc.nonuniform_quantize(x, pts, c['bucket'], 'midpoint')
+        assert np.array_equal(r['idx'], G.arr('n', i, 'idx_pre')) and np.array_equal(r['q'], G.arr('n', i, 'q_pre')), (i, c)
+        got, ab = oc.point_grad(G.arr('n', i, 'g'), G.arr('n', i, 'idx_pre'), G.arr('n', i, 'alpha'), c['bucket'], c['k'])
+        ref = G.arr('n', i, 'gp').astype(np.float64)
+        assert np.all(np.abs(got - ref) <= 2e-6 * ab + 1e-30), (i, c)
+
+
+def test_c_ste_vs_numpy_and_golden(golden_ste):
+    G = golden_ste
+    for i, c in enumerate(G.meta):
+        x, g = G.arr('s', i, 'x'), G.arr('s', i, 'g')
+        out = oc.ste_complicated_backward(x, g, c['s'], c['bucket'])
+        assert np.array_equal(out, onp.ste_complicated_backward(x, g, c['s'], c['bucket'])), (i, c)
+        scale = np.abs(g).sum() / g.size * c['bucket']
+        assert np.allclose(out, G.arr('s', i, 'gout'), rtol=0, atol=3e-6 * scale)
+
+
+def test_c_big_checksums_from_reference(golden_big):
+    """Full pipelines at 100k..1M elements: histograms of the integer level path must match the
+    reference exactly; float64 checksums of q to ~1e-12 relative (same fp32 values summed)."""
+    import torch
+    for c in golden_big:
+        x = torch.randn(c['n'], generator=torch.Generator().manual_seed(c['seed'])).numpy()
+        if c['op'] == 'uniform':
+            assert abs(float(x.astype(np.float64).sum()) - c['x_sum']) < 1e-6     # same input stream
+            r = oc.uniform_quantize(x, c['s'], c['bucket'])
+            assert np.bincount(r['lev'], minlength=c['s']).tolist() == c['hist']
+            s1, s2 = oc.checksum(r['q'])
+            assert abs(s1 - c['sum_q']) <= 1e-9 * max(1.0, abs(c['sum_q2'])) and abs(s2 - c['sum_q2']) <= 1e-9 * c['sum_q2']
+            assert [float(v) for v in r['q'][:5]] == c['q_head'] and [float(v) for v in r['q'][-3:]] == c['q_tail']
+        else:
+            pts = np.array(c['points'], dtype=np.float32)
+            r = oc.nonuniform_quantize(x, pts, c['bucket'], 'distance')
+            assert np.bincount(r['idx'], minlength=c['k']).tolist() == c['hist']
+            s1, _ = oc.checksum(r['q'])
+            assert abs(s1 - c['sum_q']) <= 1e-6 * max(1.0, abs(c['sum_q']))
+
+
+def test_c_random_vs_numpy():
+    rng = np.random.RandomState(0)
+    for n, bucket, s in [(1, 256, 16), (255, 256, 4), (256, 256, 2), (10000, 256, 16), (10007, 100, 16),
+                         (5000, None, 256), (777, 7, 3)]:
+        x = rng.randn(n).astype(np.float32)
+        a = onp.uniform_quantize(x, s, bucket)
+        b = oc.uniform_quantize(x, s, bucket)
+        assert np.array_equal(a['q'], b['q']) and np.array_equal(a['lev'].reshape(-1)[:n], b['lev'])
+        assert np.array_equal(a['imin'].reshape(-1), b['imin']) and np.array_equal(a['imax'].reshape(-1), b['imax'])
+    assert oc.max_threads() >= 1
