@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the fake-quantization hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: one call of
+quantization.uniformQuantization(x, s=16, bucket_size=256) on a 64 Mi-element fp32 tensor
+(BASELINE.json: "quantize-dequantize GB/s (64M fp32, 4-bit)"), through the public Python API
+(allocation of the result + one HIP kernel launch through the C ABI).  Inputs are resident in
+HBM; four input tensors and four live outputs are rotated so that every call streams 512 MiB
+through HBM and cannot be served from the 256 MiB Infinity Cache.
+
+Multi-GPU (one process per GPU): the path shards by tensor -- every rank quantizes its own
+tensors, no collective in the data path -- so scaling is "weak" and value = total bytes of all
+ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      achieved algorithmic GB/s of the dominant kernel (8 B/element: 4 read + 4 written,
+                SURVEY.md 8d) from HIP-event timing of the timed region, against the 8 TB/s peak
+  cpu_baseline  the same algorithm on the host cores (C port of the reference, OpenMP) on a
+                bounded sample, and the op-for-op torch CPU port of the reference next to it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+N_ELEM = 64 * 1024 * 1024
+LEVELS = 16
+BUCKET = 256
+ALGO_BYTES_PER_ELEM = 8            # 4 B read + 4 B written (alpha/beta side outputs: 0.03 B/elem, not counted)
+HBM_PEAK_GBPS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_ROTATE = 4
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(x_host):
+    """The reference's algorithm on the host cores, same workload, bounded sample."""
+    import numpy as np
+    from oracle import oracle_c
+    from oracle.torch_port import uniform_quantize_torch_ops
+    oracle_c.build()
+    cores = oracle_c.max_threads()
+    xn = x_host.numpy()
+    n = xn.size
+    oracle_c.uniform_quantize(xn, LEVELS, BUCKET, want_idx=False, want_lev=False)       # warm-up
+    times = []
+    t_end = time.time() + 12.0
+    while len(times) < 10 and (time.time() < t_end or len(times) < 3):
+        t0 = time.perf_counter()
+        oracle_c.uniform_quantize(xn, LEVELS, BUCKET, want_idx=False, want_lev=False)
+        times.append(time.perf_counter() - t0)
+    best, med = min(times), float(np.median(times))
+    out = {
+        'value': round(ALGO_BYTES_PER_ELEM * n / best / 1e9, 3), 'unit': 'GB/s', 'cores': cores, 'kind': 'port',
+        'sample': '%d runs of the full workload (N=%d fp32, s=%d, bucket=%d); C port of the reference '
+                  'algorithm (oracle/qd_oracle.c, OpenMP over buckets); min %.4f s, median %.4f s'
+                  % (len(times), n, LEVELS, BUCKET, best, med),
+        'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(),
+    }
+    # the reference's own op chain (multi-threaded torch CPU ops), restated in oracle/torch_port.py
+    torch.set_num_threads(os.cpu_count() or 1)
+    uniform_quantize_torch_ops(x_host, LEVELS, BUCKET)
+    tt = []
+    t_end = time.time() + 12.0
+    while len(tt) < 5 and (time.time() < t_end or len(tt) < 2):
+        t0 = time.perf_counter()
+        uniform_quantize_torch_ops(x_host, LEVELS, BUCKET)
+        tt.append(time.perf_counter() - t0)
+    out['torch_ops_port'] = {
+        'value': round(ALGO_BYTES_PER_ELEM * n / min(tt) / 1e9, 3), 'unit': 'GB/s',
+        'threads': torch.get_num_threads(),
+        'sample': '%d runs, min %.4f s, median %.4f s; same sequence of torch CPU ops as '
+                  'quantization/quant_functions.py:155-194' % (len(tt), min(tt), float(np.median(tt))),
+    }
+    return out
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get('k_bucket_vec_hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)        # "nccl" is RCCL on ROCm
+    n_gpus = world if distributed else 1
+
+    import quantization
+    from quantized_distillation_amd import _lib
+    _lib.load()
+
+    gen = torch.Generator().manual_seed(1000 * rank)
+    x_host = torch.randn(N_ELEM, generator=gen)
+    xs = [x_host.to(dev)]
+    for i in range(1, N_ROTATE):
+        xs.append(torch.randn(N_ELEM, generator=gen).to(dev))
+    live = [None] * N_ROTATE
+
+    def step(i):
+        q, _sf = quantization.uniformQuantization(xs[i % N_ROTATE], LEVELS, bucket_size=BUCKET)
+        live[i % N_ROTATE] = q            # keep the last outputs alive: rotating output buffers
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    event_ms = ev0.elapsed_time(ev1)
+
+    if distributed:
+        t = torch.tensor([elapsed, event_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, event_ms = float(t[0]), float(t[1])
+
+    # parity spot check in the same run (rank 0): bit-exact against the CPU oracle
+    parity = None
+    cpu = None
+    if rank == 0:
+        import numpy as np
+        from oracle import oracle_c
+        oracle_c.build()
+        ref = oracle_c.uniform_quantize(x_host.numpy(), LEVELS, BUCKET, want_idx=False, want_lev=False)
+        q, sf = quantization.uniformQuantization(xs[0], LEVELS, bucket_size=BUCKET)
+        parity = bool(np.array_equal(q.cpu().numpy(), ref['q']) and
+                      np.array_equal(sf.alpha.cpu().numpy().reshape(-1), ref['alpha']))
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(x_host)
+
+    # copy ceiling on this very GPU: torch's own device-to-device copy of the same 256 MiB tensors
+    ya = torch.empty_like(xs[0])
+    for _ in range(3):
+        ya.copy_(xs[1])
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    c0.record()
+    for i in range(20):
+        live[i % N_ROTATE].copy_(xs[i % N_ROTATE])
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbps = ALGO_BYTES_PER_ELEM * N_ELEM * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+
+    if rank == 0:
+        bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM
+        total_bytes = bytes_per_launch * args.steps * n_gpus
+        value = total_bytes / elapsed / 1e9
+        kernel_us = event_ms * 1e3 / args.steps
+        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+        out = {
+            'metric': 'quantize_dequantize_GBps_64M_fp32_4bit',
+            'value': round(value, 2), 'unit': 'GB/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed * 1e3 / args.steps, 5), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': 'quantization.uniformQuantization(x, s=16, type_of_scaling="linear", bucket_size=256), '
+                            'x = randn(64Mi) fp32 per GPU, deterministic rounding (BASELINE configs[1] hot path at the '
+                            "metric's headline size)",
+                'n_elements_per_gpu': N_ELEM, 'levels': LEVELS, 'bucket_size': BUCKET,
+                'algorithmic_bytes_per_element': ALGO_BYTES_PER_ELEM, 'rotating_buffers': N_ROTATE,
+                'parallelism': 'independent tensors per rank (no data-path collective)' if n_gpus > 1 else 'single GPU',
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'k_bucket_vec<MODE_QDQ,16,4>',
+                'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': load_pmc_traffic(),
+                'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
+                'timing': 'HIP events on the launch stream around the %d timed launches (includes inter-launch gaps)' % args.steps,
+                'copy_ceiling_GBps': round(copy_gbps, 1),
+            },
+            'cpu_baseline': cpu,
+            'parity_bit_exact_vs_oracle': parity,
+            'device': torch.cuda.get_device_name(dev),
+        }
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,156 @@
+/* qd_hip.h -- C ABI of libqd_hip.so, the MI355X (gfx950) fake-quantization kernels.
+ *
+ * This is the drop-in boundary of the hot path.  The reference
+ * (antspy/quantized_distillation) has no FFI layer: its hot path is the Python module
+ * `quantization` (quantization/__init__.py:4-8), a chain of unfused torch ops.  Each entry point
+ * below replaces the chain of reference ops cited next to it (paths relative to the reference
+ * root); the Python package `quantization` shipped in this repository keeps the reference's
+ * signatures and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host";
+ *   - tensors are contiguous fp32; `n` is the number of real elements;
+ *   - `bucket`: elements per bucket, or 0 for "bucket_size=None" (one bucket = whole tensor);
+ *     the bucket view follows quantization/help_functions.py:67-94:
+ *       n <  bucket            -> 1 bucket of n elements
+ *       n %  bucket == 0       -> n/bucket buckets
+ *       otherwise              -> ceil(n/bucket) buckets, the last one padded with copies of
+ *                                 x[n-1] (padding never changes min/max, so kernels ignore it);
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), never allocate,
+ *     never synchronise with the host;
+ *   - return value: 0 on success, a positive hipError_t if a launch failed, or a negative
+ *     QD_ERR_* code for argument errors.  qd_error_string() describes either.
+ *   - optional outputs may be NULL.
+ *   - `mean`: optional device scalar subtracted from every element before anything else
+ *     (subtract_mean=True, quant_functions.py:66-68) and added back at the end (:148).
+ *   - `clamp`/`max_element`: if clamp != 0, values are clamped to [-max_element, max_element]
+ *     after the mean subtraction (quant_functions.py:72-74).
+ */
+#ifndef QD_HIP_H
+#define QD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_ERR_INVALID_ARGUMENT (-1)
+#define QD_ERR_WORKSPACE_TOO_SMALL (-2)
+#define QD_ERR_UNSUPPORTED (-3)
+
+/* nearest-point assignment rules (quant_functions.py:267-273 vs :531-573) */
+#define QD_ASSIGN_DISTANCE 0
+#define QD_ASSIGN_MIDPOINT 1
+
+/* tie rule of the 'complicated' STE backward */
+#define QD_STE_TIE_REFERENCE 0 /* first element at the top/bottom LEVEL of the quantized bucket */
+#define QD_STE_TIE_TRUE_ARG 1  /* true argmax/argmin of the input                               */
+
+/* Library identification: ABI version (bumped on incompatible changes) and target arch. */
+int qd_abi_version(void);
+const char* qd_target_arch(void);
+const char* qd_error_string(int code);
+
+/* Bytes of device scratch the reductions need (global min/max, mean, point gradient).
+ * One buffer of this size per stream is enough; contents need no initialisation. */
+size_t qd_workspace_bytes(void);
+
+/* Number of buckets / padded length of the bucket view (help_functions.py:67-94). Host only. */
+int64_t qd_num_buckets(int64_t n, int64_t bucket);
+int64_t qd_padded_length(int64_t n, int64_t bucket);
+
+/* mean_out[0] = mean(x) (float64 accumulation, one rounding).  Replaces tensor.mean(),
+ * quant_functions.py:67. */
+int qd_mean_f32(const float* x, int64_t n, float* mean_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K1/K1g: uniformQuantization, linear scaling (quant_functions.py:155-194 with
+ * ScalingFunction.scale_down :56-107 and inv_scale_down :131-152 fused):
+ *     alpha_b = max_b - min_b (alpha < 1e-10 -> 1), beta_b = min_b
+ *     q = rint((x - beta)/alpha * (levels-1)) / (levels-1) * alpha + beta   [each op rounded]
+ * x, q: [n] (q may alias x: modify_in_place).  alpha, beta: [num_buckets] optional outputs.
+ * level_idx: optional [n] uint8 output of the integer level rint(u*(levels-1)) (levels <= 256).
+ * stochastic != 0 selects the stochastic-rounding branch (:174-187) with a counter-based
+ * in-kernel generator keyed by (seed, element index).
+ * workspace is only used when the tensor is a single bucket (bucket == 0 or n < bucket). */
+int qd_uniform_f32(const float* x, float* q, int64_t n, int64_t bucket, int levels, float* alpha, float* beta,
+                   uint8_t* level_idx, const float* mean, int clamp, float max_element, int stochastic,
+                   uint64_t seed, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K2: ScalingFunction.scale_down, linear (quant_functions.py:56-107).  u has the PADDED bucket
+ * layout: qd_padded_length(n, bucket) elements; padding entries hold the scaled last element,
+ * exactly as the reference's cat-then-scale produces.  u may alias x only when no padding is
+ * needed.  alpha, beta: [num_buckets] (required: they are what inverts the scaling). */
+int qd_scale_down_f32(const float* x, float* u, int64_t n, int64_t bucket, float* alpha, float* beta,
+                      const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* K3: ScalingFunction.inv_scale_down, linear (quant_functions.py:131-152): y = u*alpha + beta
+ * (+ mean), padding dropped.  u: padded layout; y: [n]; y may alias u. */
+int qd_inv_scale_f32(const float* u, float* y, int64_t n, int64_t bucket, const float* alpha, const float* beta,
+                     const float* mean, void* stream);
+
+/* First-occurrence arg-min / arg-max of each bucket, relative to the bucket start (int64), the
+ * idx_min_rows / idx_max_rows of ScalingFunction (quant_functions.py:85-90,103-104).  Computed
+ * on demand only (nothing on the per-step path reads them except the 'complicated' STE). */
+int qd_bucket_argminmax_f32(const float* x, int64_t n, int64_t bucket, const float* mean, int clamp,
+                            float max_element, int64_t* argmin, int64_t* argmax, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* K4/K5: nearest-point (non-uniform) quantization (quant_functions.py:196-290).
+ *   prescaled == 0: x is the raw tensor [n]; it is scaled per bucket first (alpha/beta are
+ *                   OUTPUTS, [num_buckets]);
+ *   prescaled != 0: x is u in the unpadded layout [n], already scaled; alpha/beta are INPUTS
+ *                   (the per-step path of differentiable quantization: the tensor is frozen,
+ *                   only `points` change, quant_functions.py:449-469).
+ * points: [k] sorted ascending, device.  assign_mode: QD_ASSIGN_DISTANCE (searchsorted-left +
+ * strictly-closer-lower rule, :267-273) or QD_ASSIGN_MIDPOINT (#{midpoints <= u}, the
+ * SearchSorted.query formulation, :531-573).
+ * q: [n] = points[idx]*alpha + beta (+mean).  idx: optional, idx_bytes 8 (int64, what the
+ * reference API returns) or 1 (uint8, k <= 256). */
+int qd_nearest_point_f32(const float* x, int prescaled, const float* points, int k, int assign_mode, float* q,
+                         void* idx, int idx_bytes, int64_t n, int64_t bucket, float* alpha, float* beta,
+                         const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* K6: nonUniformQuantization_variable.backward (quant_functions.py:471-506):
+ *     grad_points[j] = sum_{i : idx_i == j} g_i * alpha_bucket(i)
+ * Deterministic two-stage reduction (fixed order, no atomics).  idx_bytes 8 or 1. */
+int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const float* alpha, int64_t n, int64_t bucket,
+                      int k, float* grad_points, void* workspace, size_t workspace_bytes, void* stream);
+
+/* K7: 'complicated' straight-through backward of uniformQuantization_variable
+ * (quant_functions.py:319-406, intended math): per bucket
+ *     S_b = sum_i g_i*(qs_i - u_i);  out = g;  out[jmax_b] += S_b;  out[jmin_b] -= S_b.
+ * Requires bucket > 0 (as the reference does, :332-334).  out may alias g. */
+int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64_t n, int64_t bucket, int levels,
+                               int tie_mode, void* stream);
+
+/* K8: 'truncated' STE (cnn_models/conv_forward_model.py:240-241,263-264):
+ * qd_clamp_f32: w = clamp(w, -limit, limit) in place; qd_truncated_ste_f32: grad[|w| > limit] = 0. */
+int qd_clamp_f32(float* w, int64_t n, float limit, void* stream);
+int qd_truncated_ste_f32(const float* w, float* grad, int64_t n, float limit, void* stream);
+
+/* Multi-tensor K1: one launch quantizes every parameter tensor of a model (the per-step loop
+ * `for p in model.parameters(): p.data = uniformQuantization(p.data, s, bucket_size=...)[0]`,
+ * cnn_models/conv_forward_model.py:235-247).  `table` is a DEVICE array of descriptors built
+ * once per model; each tensor is bucketed independently with the same `bucket`/`levels`.
+ * bucket must be > 0. */
+typedef struct QdTensorDesc {
+    const float* x;      /* master weights            */
+    float* q;            /* quantized shadow (may alias x) */
+    int64_t n;           /* elements                   */
+    int64_t first_tile;  /* prefix sum of work tiles (filled by qd_multi_plan) */
+} QdTensorDesc;
+
+/* Host helper: fills first_tile of `ntensors` host descriptors, returns the total tile count
+ * (pass it to qd_multi_uniform_f32 as total_tiles). */
+int64_t qd_multi_plan(QdTensorDesc* host_table, int ntensors, int64_t bucket);
+int qd_multi_uniform_f32(const QdTensorDesc* table, int ntensors, int64_t total_tiles, int64_t bucket, int levels,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QD_HIP_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of libqd_hip.so (C ABI: include/qd_hip.h).
+
+PyTorch is used only for device memory and the current HIP stream; every kernel is launched
+through the C ABI with raw device pointers.  Loading fails loudly when the library has not been
+built -- there is no fallback implementation.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libqd_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
+
+_lib = None
+_lock = threading.Lock()
+
+c_f = ctypes.c_void_p          # device float*
+c_p = ctypes.c_void_p
+i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size = ctypes.c_size_t
+u64 = ctypes.c_uint64
+
+
+class QdTensorDesc(ctypes.Structure):
+    """Mirror of `struct QdTensorDesc` in include/qd_hip.h."""
+    _fields_ = [('x', ctypes.c_void_p), ('q', ctypes.c_void_p), ('n', ctypes.c_int64),
+                ('first_tile', ctypes.c_int64)]
+
+
+# symbol -> (restype, argtypes); every symbol declared in include/qd_hip.h must be listed here
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    'qd_abi_version': (c_int, []),
+    'qd_target_arch': (ctypes.c_char_p, []),
+    'qd_error_string': (ctypes.c_char_p, [c_int]),
+    'qd_workspace_bytes': (c_size, []),
+    'qd_num_buckets': (i64, [i64, i64]),
+    'qd_padded_length': (i64, [i64, i64]),
+    'qd_mean_f32': (c_int, [c_f, i64, c_f, c_p, c_size, c_p]),
+    'qd_uniform_f32': (c_int, [c_f, c_f, i64, i64, c_int, c_f, c_f, c_p, c_f, c_int, c_float, c_int, u64,
+                               c_p, c_size, c_p]),
+    'qd_scale_down_f32': (c_int, [c_f, c_f, i64, i64, c_f, c_f, c_f, c_int, c_float, c_p, c_size, c_p]),
+    'qd_inv_scale_f32': (c_int, [c_f, c_f, i64, i64, c_f, c_f, c_f, c_p]),
+    'qd_bucket_argminmax_f32': (c_int, [c_f, i64, i64, c_f, c_int, c_float, c_p, c_p, c_p, c_size, c_p]),
+    'qd_nearest_point_f32': (c_int, [c_f, c_int, c_f, c_int, c_int, c_f, c_p, c_int, i64, i64, c_f, c_f, c_f,
+                                     c_int, c_float, c_p, c_size, c_p]),
+    'qd_point_grad_f32': (c_int, [c_f, c_p, c_int, c_f, i64, i64, c_int, c_f, c_p, c_size, c_p]),
+    'qd_ste_bucket_backward_f32': (c_int, [c_f, c_f, c_f, i64, i64, c_int, c_int, c_p]),
+    'qd_clamp_f32': (c_int, [c_f, i64, c_float, c_p]),
+    'qd_truncated_ste_f32': (c_int, [c_f, c_f, i64, c_float, c_p]),
+    'qd_multi_plan': (i64, [ctypes.POINTER(QdTensorDesc), c_int, i64]),
+    'qd_multi_uniform_f32': (c_int, [c_p, c_int, i64, i64, c_int, c_p]),
+}
+
+
+class QdLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libqd_hip.so (once).  Raises QdLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise QdLibraryMissing(
+                'quantized_distillation_amd: %s is missing. Build the HIP extension first: '
+                'python -c "import __graft_entry__ as g; g.build()" (needs hipcc, gfx950). '
+                'There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError = ABI mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.qd_abi_version() != 1:
+            raise RuntimeError('libqd_hip.so ABI version %d, expected 1' % lib.qd_abi_version())
+        _lib = lib
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().qd_error_string(code)
+        raise RuntimeError('qd_hip: %s (code %d)' % (msg.decode() if msg else '?', code))
+
+
+# ---------------------------------------------------------------- torch plumbing (memory, stream)
+_workspaces = {}
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(device):
+    """One scratch buffer per (device, stream); kernels on a stream are ordered, so sharing it
+    between consecutive calls on that stream is safe."""
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = int(load().qd_workspace_bytes())
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def require_device_f32(t, what='tensor'):
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %r' % (what, type(t)))
+    if not t.is_cuda:
+        raise RuntimeError('quantized_distillation_amd: %s must live on a HIP device (got %s); '
+                           'this package has no CPU path' % (what, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32 (the reference path is fp32-only), got %s' % (what, t.dtype))

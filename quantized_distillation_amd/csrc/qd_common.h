@@ -1,0 +1,210 @@
+// qd_common.h -- device helpers shared by the gfx950 fake-quantization kernels.
+//
+// Everything here is written for CDNA4 wave64: DPP row rotations for the 16-lane reductions,
+// ds_bpermute (via __shfl_xor) only for the two cross-row steps, 16-byte non-temporal global
+// accesses.  Compile with -ffp-contract=off: the reference rounds every fp32 op separately.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int64_t l2 __attribute__((ext_vector_type(2)));
+
+#define QD_TOL_DIFF_ZERO 1e-10f  // reference: quantization/quant_functions.py:40
+
+namespace qd {
+
+// ---- DPP row rotations: lane i of each 16-lane row reads lane (i + s) mod 16 of its row ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+#define QD_ROR8 0x128
+#define QD_ROR4 0x124
+#define QD_ROR2 0x122
+#define QD_ROR1 0x121
+
+// all-reduce over the 16 lanes of a DPP row (min / max are idempotent; sum uses the same tree)
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, dpp_f<QD_ROR8>(v));
+    v = fminf(v, dpp_f<QD_ROR4>(v));
+    v = fminf(v, dpp_f<QD_ROR2>(v));
+    v = fminf(v, dpp_f<QD_ROR1>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<QD_ROR8>(v));
+    v = fmaxf(v, dpp_f<QD_ROR4>(v));
+    v = fmaxf(v, dpp_f<QD_ROR2>(v));
+    v = fmaxf(v, dpp_f<QD_ROR1>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v = v + dpp_f<QD_ROR8>(v);
+    v = v + dpp_f<QD_ROR4>(v);
+    v = v + dpp_f<QD_ROR2>(v);
+    v = v + dpp_f<QD_ROR1>(v);
+    return v;
+}
+__device__ __forceinline__ int row16_imin(int v) {
+    v = min(v, dpp_i<QD_ROR8>(v));
+    v = min(v, dpp_i<QD_ROR4>(v));
+    v = min(v, dpp_i<QD_ROR2>(v));
+    v = min(v, dpp_i<QD_ROR1>(v));
+    return v;
+}
+
+// all-reduce over the 64 lanes of a wave: row step by DPP, the two cross-row steps by bpermute
+__device__ __forceinline__ float wave_min(float v) {
+    v = row16_min(v);
+    v = fminf(v, __shfl_xor(v, 16));
+    v = fminf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    v = v + __shfl_xor(v, 16);
+    v = v + __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
+    return v;
+}
+__device__ __forceinline__ long long wave_min_ll(long long v) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        long long o = __shfl_xor(v, s);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// block-wide all-reduce helpers (blockDim.x a multiple of 64, <= 1024); `red` is LDS scratch of
+// >= 32 floats; results are broadcast to every thread.
+__device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red) {
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int nw = blockDim.x >> 6;
+    if (nw == 1) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // protect `red` from a previous use
+    if (lane == 0) { red[w] = mn; red[16 + w] = mx; }
+    __syncthreads();
+    float a = red[0], b = red[16];
+    for (int i = 1; i < nw; ++i) { a = fminf(a, red[i]); b = fmaxf(b, red[16 + i]); }
+    mn = a; mx = b;
+}
+
+// ---- per-element preparation: mean subtraction then clamp (quant_functions.py:66-74) ----
+struct Prep {
+    float mean;  // 0 when subtract_mean is off: x - 0 is exact
+    float me;    // +inf when max_element is off
+};
+__device__ __forceinline__ float prep(float x, const Prep& p) {
+    x = x - p.mean;
+    x = x > p.me ? p.me : x;
+    x = x < -p.me ? -p.me : x;
+    return x;
+}
+__device__ __forceinline__ f4 prep4(f4 v, const Prep& p) {
+    v.x = prep(v.x, p); v.y = prep(v.y, p); v.z = prep(v.z, p); v.w = prep(v.w, p);
+    return v;
+}
+
+// alpha/beta of a bucket from its min/max (quant_functions.py:91-99)
+__device__ __forceinline__ void alpha_beta(float mn, float mx, float& a, float& b) {
+    a = mx - mn;
+    a = a < QD_TOL_DIFF_ZERO ? 1.0f : a;
+    b = mn;
+}
+
+// ---- the k-level quantize-dequantize of one element (quant_functions.py:106-107,189-191,142-148)
+// Seven separately rounded fp32 ops; both divisions are IEEE-correct (no reciprocal shortcut):
+// the level index rint(u*(s-1)) must match the reference bit for bit.
+__device__ __forceinline__ float qdq(float v, float a, float b, float sm1, float mean, float& level) {
+    float u = v - b;
+    u = u / a;
+    float t = u * sm1;
+    float r = rintf(t);
+    level = r;
+    float w = r / sm1;
+    float y = w * a;
+    y = y + b;
+    y = y + mean;
+    return y;
+}
+
+// ---- Philox4x32-10 counter-based generator for the stochastic-rounding branch ----
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+// four uniforms in [0,1) for the 4 consecutive elements starting at element index e (e % 4 == 0
+// on the vector paths; scalar paths use component e & 3 of block e >> 2)
+__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t block, float (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)block, (uint32_t)(block >> 32), 0x51ed270bu, 0x2545f491u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
+}
+// stochastic variant (quant_functions.py:174-187): floor + Bernoulli(frac)
+__device__ __forceinline__ float qdq_stochastic(float v, float a, float b, float sm1, float mean, float rnd,
+                                                float& level) {
+    float u = v - b;
+    u = u / a;
+    float t = u * sm1;     // == probabilities before the subtraction (same product)
+    float l = floorf(t);
+    float p = t - l;
+    float w = l / sm1;
+    float inc = (rnd <= p) ? (1.0f / sm1) : 0.0f;
+    level = l + ((rnd <= p) ? 1.0f : 0.0f);
+    w = w + inc;
+    float y = w * a;
+    y = y + b;
+    y = y + mean;
+    return y;
+}
+
+// ---- sorted-array searches over LDS (uniform trip count, branch-free) ----
+// count of a[j] <  u (lower bound) when UPPER == false; count of a[j] <= u when UPPER == true
+template <bool UPPER>
+__device__ __forceinline__ int count_before(const float* a, int n, float u) {
+    int lo = 0;
+    while (n > 1) {
+        const int half = n >> 1;
+        const float v = a[lo + half - 1];
+        const bool c = UPPER ? (v <= u) : (v < u);
+        lo = c ? lo + half : lo;
+        n -= half;
+    }
+    if (n == 1) {
+        const float v = a[lo];
+        const bool c = UPPER ? (v <= u) : (v < u);
+        lo += c ? 1 : 0;
+    }
+    return lo;
+}
+
+}  // namespace qd

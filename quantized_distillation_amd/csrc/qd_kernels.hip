@@ -1,0 +1,1087 @@
+// qd_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the fake-quantization hot path of
+// antspy/quantized_distillation, behind the C ABI of include/qd_hip.h.
+//
+// Reference being replaced (paths relative to the reference root):
+//   quantization/quant_functions.py:56-152   ScalingFunction.scale_down / inv_scale_down
+//   quantization/quant_functions.py:155-194  uniformQuantization
+//   quantization/quant_functions.py:196-290  nonUniformQuantization (+ SearchSorted :509-573)
+//   quantization/quant_functions.py:319-406  uniformQuantization_variable.backward
+//   quantization/quant_functions.py:471-506  nonUniformQuantization_variable.backward
+//   quantization/help_functions.py:67-94     create_bucket_tensor (semantics folded in)
+//
+// Design: this is HBM-bound elementwise + small-reduction work, so there is no
+// MFMA and no LDS staging of data.  A bucket of 256 fp32 is 1 KiB; one DPP row (16 lanes) owns
+// one bucket and holds it in registers as 4 x float4, so a wave64 streams 4 buckets (4 KiB) per
+// iteration with 16-byte coalesced non-temporal loads, reduces min/max with 4 DPP row rotations
+// (no LDS, no bpermute), and writes the result once: 8 B/element of HBM traffic instead of the
+// reference's ~12 unfused passes.
+//
+// No CUDA compatibility layer, no dual code paths: gfx950 only.
+
+#include "qd_common.h"
+#include "../../include/qd_hip.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+using namespace qd;
+
+namespace {
+
+enum Mode { MODE_QDQ = 0, MODE_SCALE = 1, MODE_NEAREST = 2 };
+
+constexpr int kMaxPoints = 1024;        // LDS table of quantization points
+constexpr int kPartialBlocks = 1024;    // stage-1 blocks of every two-stage reduction
+
+struct KParams {
+    const float* x;      // input [n]
+    float* out;          // QDQ/NEAREST: [n]; SCALE: [padded]
+    int64_t n;
+    int64_t row;         // elements per bucket row (>= 1)
+    int64_t nb;          // number of buckets
+    float* alpha;        // [nb] outputs, or inputs when prescaled
+    float* beta;
+    const float* mean;   // device scalar or null
+    float me;            // clamp limit, +inf when off
+    float sm1;           // levels - 1
+    uint8_t* lev8;       // optional [n] level index
+    void* idx;           // NEAREST: optional index output
+    int idx_bytes;       // 8 or 1
+    const float* pts;    // NEAREST: [k] sorted points
+    int k;
+    int assign_mode;
+    int prescaled;       // NEAREST: x is already u, alpha/beta are inputs
+    int stochastic;
+    uint64_t seed;
+    int64_t nvec;        // number of leading full buckets handled by the vector path
+};
+
+// LDS-resident point table (+ midpoints, quant_functions.py:533)
+struct PointTable {
+    float pts[kMaxPoints];
+    float mid[kMaxPoints];
+};
+
+__device__ __forceinline__ void load_points(PointTable& T, const float* pts, int k) {
+    for (int j = threadIdx.x; j < k; j += blockDim.x) T.pts[j] = pts[j];
+    __syncthreads();
+    for (int j = threadIdx.x; j + 1 < k; j += blockDim.x) {
+        float d = T.pts[j + 1] - T.pts[j];   // np.diff(k)
+        d = d / 2.0f;                        //  / 2
+        T.mid[j] = T.pts[j] + d;             // k[:-1] + ...
+    }
+    __syncthreads();
+}
+
+// nearest point of u (quant_functions.py:267-273 or :531-573)
+__device__ __forceinline__ int assign_point(const PointTable& T, int k, int mode, float u) {
+    if (mode == QD_ASSIGN_MIDPOINT) return count_before<true>(T.mid, k - 1, u);
+    int i = count_before<false>(T.pts, k, u);        // searchsorted(side='left')
+    i = i > k - 1 ? k - 1 : i;                       // .clip(max=k-1)
+    if (i > 0) {
+        const float dl = fabsf(u - T.pts[i - 1]);
+        const float dh = fabsf(u - T.pts[i]);
+        i -= (dl < dh) ? 1 : 0;                      // strictly closer to the lower point
+    }
+    return i;
+}
+
+// ---- per-element transform shared by every bucket kernel -----------------------------------
+// v: prepared value (mean subtracted, clamped) -- or u itself when prescaled.
+// e: global element index (for the side outputs and the random stream).
+template <int MODE>
+__device__ __forceinline__ float transform(const KParams& p, const PointTable* T, float v, float a, float b,
+                                           float mean, float rnd, float& side) {
+    if (MODE == MODE_QDQ) {
+        return p.stochastic ? qdq_stochastic(v, a, b, p.sm1, mean, rnd, side) : qdq(v, a, b, p.sm1, mean, side);
+    } else if (MODE == MODE_SCALE) {
+        float u = v - b;
+        u = u / a;
+        return u;
+    } else {
+        float u = v;
+        if (!p.prescaled) { u = v - b; u = u / a; }
+        const int i = assign_point(*T, p.k, p.assign_mode, u);
+        side = (float)i;
+        float y = T->pts[i] * a;
+        y = y + b;
+        y = y + mean;
+        return y;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_side1(const KParams& p, int64_t e, float side) {
+    if (MODE == MODE_QDQ) {
+        if (p.lev8) p.lev8[e] = (uint8_t)(int)side;
+    } else if (MODE == MODE_NEAREST) {
+        if (p.idx) {
+            if (p.idx_bytes == 8) ((int64_t*)p.idx)[e] = (int64_t)side;
+            else ((uint8_t*)p.idx)[e] = (uint8_t)(int)side;
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_side4(const KParams& p, int64_t e, const float (&s)[4]) {
+    if (MODE == MODE_QDQ) {
+        if (p.lev8) {
+            const uint32_t pk = (uint32_t)(int)s[0] | ((uint32_t)(int)s[1] << 8) | ((uint32_t)(int)s[2] << 16) |
+                                ((uint32_t)(int)s[3] << 24);
+            *(uint32_t*)(p.lev8 + e) = pk;
+        }
+    } else if (MODE == MODE_NEAREST) {
+        if (p.idx) {
+            if (p.idx_bytes == 8) {
+                l2* o = (l2*)((int64_t*)p.idx + e);
+                l2 a = {(int64_t)s[0], (int64_t)s[1]}, b = {(int64_t)s[2], (int64_t)s[3]};
+                __builtin_nontemporal_store(a, o);
+                __builtin_nontemporal_store(b, o + 1);
+            } else {
+                const uint32_t pk = (uint32_t)(int)s[0] | ((uint32_t)(int)s[1] << 8) |
+                                    ((uint32_t)(int)s[2] << 16) | ((uint32_t)(int)s[3] << 24);
+                *(uint32_t*)((uint8_t*)p.idx + e) = pk;
+            }
+        }
+    }
+}
+
+// ---- 16 lanes (one DPP row) process one arbitrary bucket [lo, hi): scalar accesses, two passes
+// (the second pass re-reads from L1/L2).  Used for the ragged last bucket, short buckets and
+// the multi-tensor kernel's unaligned cases.  `l` = lane index inside the row (0..15).
+template <int MODE>
+__device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable* T, int64_t bkt, int64_t lo,
+                                             int64_t hi, int l, const Prep& pp) {
+    float a, b;
+    if (MODE == MODE_NEAREST && p.prescaled) {
+        a = p.alpha[bkt]; b = p.beta[bkt];
+    } else {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int64_t i = lo + l; i < hi; i += 16) {
+            const float v = prep(p.x[i], pp);
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+        mn = row16_min(mn); mx = row16_max(mx);
+        alpha_beta(mn, mx, a, b);
+        if (l == 0) {
+            if (p.alpha) p.alpha[bkt] = a;
+            if (p.beta) p.beta[bkt] = b;
+        }
+    }
+    float last = 0.0f;
+    for (int64_t i = lo + l; i < hi; i += 16) {
+        float v = p.x[i];
+        if (!(MODE == MODE_NEAREST && p.prescaled)) v = prep(v, pp);
+        float rnd = 0.0f;
+        if (MODE == MODE_QDQ && p.stochastic) {
+            float r4[4];
+            philox_uniform4(p.seed, (uint64_t)i >> 2, r4);
+            rnd = r4[i & 3];
+        }
+        float side = 0.0f;
+        const float y = transform<MODE>(p, T, v, a, b, pp.mean, rnd, side);
+        p.out[i] = y;
+        store_side1<MODE>(p, i, side);
+        last = y;
+    }
+    if (MODE == MODE_SCALE) {
+        // padding of the ragged last bucket: copies of x[n-1], scaled (help_functions.py:76-86)
+        const int64_t end = lo + p.row;
+        if (hi < end && hi == p.n && p.nb > 1) {
+            const float u_last = transform<MODE>(p, T, prep(p.x[p.n - 1], pp), a, b, pp.mean, 0.0f, last);
+            for (int64_t i = hi + l; i < end; i += 16) p.out[i] = u_last;
+        }
+    }
+}
+
+// ---- vector path: LPB lanes per bucket, V float4 per lane: bucket = LPB*V*4 elements ---------
+// LPB == 16: a DPP row owns a bucket, a wave handles 4 buckets per iteration.
+// LPB == 64: the whole wave owns a bucket (large buckets).
+template <int MODE, int LPB, int V>
+__global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
+    __shared__ PointTable Ts;
+    const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+
+    constexpr int BPW = 64 / LPB;                 // buckets per wave iteration
+    constexpr int ROW = LPB * V * 4;              // elements per bucket
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPB;                   // which bucket of the wave tile
+    const int l = lane % LPB;                     // lane inside the bucket
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ntiles = (p.nvec + BPW - 1) / BPW;
+
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+        const int64_t bkt = t * BPW + sub;
+        if (bkt < p.nvec) {
+            const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
+            const f4* src = (const f4*)(p.x + e0);
+            f4 v[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * LPB);
+            float a, b;
+            if (MODE == MODE_NEAREST && p.prescaled) {
+                a = p.alpha[bkt]; b = p.beta[bkt];
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
+                float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
+                float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+#pragma unroll
+                for (int j = 1; j < V; ++j) {
+                    mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
+                    mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+                }
+                if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
+                else { mn = wave_min(mn); mx = wave_max(mx); }
+                alpha_beta(mn, mx, a, b);
+                if (l == 0) {
+                    if (p.alpha) p.alpha[bkt] = a;
+                    if (p.beta) p.beta[bkt] = b;
+                }
+            }
+            f4* dst = (f4*)(p.out + e0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int64_t e = e0 + (int64_t)j * LPB * 4;
+                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                float side[4];
+                f4 r;
+                r.x = transform<MODE>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0]);
+                r.y = transform<MODE>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1]);
+                r.z = transform<MODE>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2]);
+                r.w = transform<MODE>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3]);
+                __builtin_nontemporal_store(r, dst + j * LPB);
+                store_side4<MODE>(p, e, side);
+            }
+        }
+    }
+
+    // buckets after the vector part (the ragged last bucket): one DPP row each, extra block
+    if (blockIdx.x == gridDim.x - 1) {
+        const int row_id = threadIdx.x >> 4;                  // 16 rows per 256-thread block
+        for (int64_t bkt = p.nvec + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
+            const int64_t lo = bkt * p.row;
+            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+            bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
+        }
+    }
+}
+
+// ---- generic path: one block per bucket, any row length / alignment --------------------------
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_bucket_generic(KParams p) {
+    __shared__ PointTable Ts;
+    __shared__ float red[32];
+    const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+    for (int64_t bkt = blockIdx.x; bkt < p.nb; bkt += gridDim.x) {
+        const int64_t lo = bkt * p.row;
+        const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+        float a, b;
+        if (MODE == MODE_NEAREST && p.prescaled) {
+            a = p.alpha[bkt]; b = p.beta[bkt];
+        } else {
+            float mn = INFINITY, mx = -INFINITY;
+            for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                const float v = prep(p.x[i], pp);
+                mn = fminf(mn, v); mx = fmaxf(mx, v);
+            }
+            block_minmax(mn, mx, red);
+            alpha_beta(mn, mx, a, b);
+            if (threadIdx.x == 0) {
+                if (p.alpha) p.alpha[bkt] = a;
+                if (p.beta) p.beta[bkt] = b;
+            }
+        }
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            float v = p.x[i];
+            if (!(MODE == MODE_NEAREST && p.prescaled)) v = prep(v, pp);
+            float rnd = 0.0f;
+            if (MODE == MODE_QDQ && p.stochastic) {
+                float r4[4];
+                philox_uniform4(p.seed, (uint64_t)i >> 2, r4);
+                rnd = r4[i & 3];
+            }
+            float side = 0.0f;
+            const float y = transform<MODE>(p, T, v, a, b, pp.mean, rnd, side);
+            p.out[i] = y;
+            store_side1<MODE>(p, i, side);
+        }
+        if (MODE == MODE_SCALE) {
+            const int64_t end = lo + p.row;
+            if (hi < end && hi == p.n && p.nb > 1) {
+                float dummy;
+                const float u_last = transform<MODE>(p, T, prep(p.x[p.n - 1], pp), a, b, pp.mean, 0.0f, dummy);
+                for (int64_t i = hi + threadIdx.x; i < end; i += blockDim.x) p.out[i] = u_last;
+            }
+        }
+    }
+}
+
+// ---- single-bucket (bucket_size=None) path for large tensors: reduce, finalize, apply --------
+// stage 1: per-block partial min/max of prep(x)
+__global__ __launch_bounds__(256) void k_minmax_partial(const float* x, int64_t n, const float* mean, float me,
+                                                        float* part /* [2*kPartialBlocks] */) {
+    __shared__ float red[32];
+    Prep pp;
+    pp.mean = mean ? *mean : 0.0f;
+    pp.me = me;
+    float mn = INFINITY, mx = -INFINITY;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)x) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const f4* x4 = (const f4*)x;
+        for (int64_t i = tid; i < n4; i += nth) {
+            const f4 v = prep4(x4[i], pp);          // plain load: keep the lines in L2/MALL for stage 3
+            mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+            mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nth) {
+            const float v = prep(x[i], pp);
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nth) {
+            const float v = prep(x[i], pp);
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+    }
+    block_minmax(mn, mx, red);
+    if (threadIdx.x == 0) { part[blockIdx.x] = mn; part[kPartialBlocks + blockIdx.x] = mx; }
+}
+
+// stage 2: one block folds the partials into alpha/beta (device scalars; no host sync, unlike
+// the reference's `alpha[0] < tol` at quant_functions.py:96)
+__global__ __launch_bounds__(256) void k_minmax_final(const float* part, int nparts, float* ab /* [2] */,
+                                                      float* alpha_out, float* beta_out) {
+    __shared__ float red[32];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        mn = fminf(mn, part[i]);
+        mx = fmaxf(mx, part[kPartialBlocks + i]);
+    }
+    block_minmax(mn, mx, red);
+    if (threadIdx.x == 0) {
+        float a, b;
+        alpha_beta(mn, mx, a, b);
+        ab[0] = a; ab[1] = b;
+        if (alpha_out) alpha_out[0] = a;
+        if (beta_out) beta_out[0] = b;
+    }
+}
+
+// stage 3: elementwise apply with the single (alpha, beta)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab) {
+    __shared__ PointTable Ts;
+    const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+    const float a = ab[0], b = ab[1];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    int64_t done = 0;
+    if (((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) == 0) {
+        const int64_t n4 = p.n >> 2;
+        const f4* x4 = (const f4*)p.x;
+        f4* o4 = (f4*)p.out;
+        for (int64_t i = tid; i < n4; i += nth) {
+            f4 v = __builtin_nontemporal_load(x4 + i);
+            if (!prescaled) v = prep4(v, pp);
+            float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)i, rnd);
+            float side[4];
+            f4 r;
+            r.x = transform<MODE>(p, T, v.x, a, b, pp.mean, rnd[0], side[0]);
+            r.y = transform<MODE>(p, T, v.y, a, b, pp.mean, rnd[1], side[1]);
+            r.z = transform<MODE>(p, T, v.z, a, b, pp.mean, rnd[2], side[2]);
+            r.w = transform<MODE>(p, T, v.w, a, b, pp.mean, rnd[3], side[3]);
+            __builtin_nontemporal_store(r, o4 + i);
+            store_side4<MODE>(p, i << 2, side);
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < p.n; i += nth) {
+        float v = p.x[i];
+        if (!prescaled) v = prep(v, pp);
+        float rnd = 0.0f;
+        if (MODE == MODE_QDQ && p.stochastic) {
+            float r4[4];
+            philox_uniform4(p.seed, (uint64_t)i >> 2, r4);
+            rnd = r4[i & 3];
+        }
+        float side = 0.0f;
+        p.out[i] = transform<MODE>(p, T, v, a, b, pp.mean, rnd, side);
+        store_side1<MODE>(p, i, side);
+    }
+}
+
+// ---- mean (float64 accumulation, fixed order) -------------------------------------------------
+__global__ __launch_bounds__(256) void k_sum_partial(const float* x, int64_t n, double* part) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)x) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const f4* x4 = (const f4*)x;
+        for (int64_t i = tid; i < n4; i += nth) {
+            const f4 v = x4[i];
+            acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nth) acc += (double)x[i];
+    } else {
+        for (int64_t i = tid; i < n; i += nth) acc += (double)x[i];
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_mean_final(const double* part, int nparts, int64_t n, float* mean_out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc += part[i];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) mean_out[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
+}
+
+// ---- inverse scaling (quant_functions.py:131-152) --------------------------------------------
+__global__ __launch_bounds__(256) void k_inv_scale(const float* u, float* y, int64_t n, int64_t row, int64_t nb,
+                                                   const float* alpha, const float* beta, const float* mean) {
+    const float m = mean ? *mean : 0.0f;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = (((((uintptr_t)u) | ((uintptr_t)y)) & 15) == 0) && (nb == 1 || (row & 3) == 0);
+    int64_t done = 0;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nth) {
+            const int64_t bkt = nb == 1 ? 0 : (i << 2) / row;
+            const float a = alpha[bkt], b = beta[bkt];
+            f4 v = __builtin_nontemporal_load((const f4*)u + i);
+            f4 r;
+            r.x = v.x * a; r.x = r.x + b; r.x = r.x + m;
+            r.y = v.y * a; r.y = r.y + b; r.y = r.y + m;
+            r.z = v.z * a; r.z = r.z + b; r.z = r.z + m;
+            r.w = v.w * a; r.w = r.w + b; r.w = r.w + m;
+            __builtin_nontemporal_store(r, (f4*)y + i);
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nth) {
+        const int64_t bkt = nb == 1 ? 0 : i / row;
+        float r = u[i] * alpha[bkt];
+        r = r + beta[bkt];
+        r = r + m;
+        y[i] = r;
+    }
+}
+
+// ---- first-occurrence arg-min/arg-max per bucket (quant_functions.py:85-90) -------------------
+// key = (value, index) compared lexicographically; block per bucket; any size (single bucket of
+// a huge tensor is handled by a grid-stride over `chunks` partial blocks + a final fold).
+struct ArgPair { float v; int64_t i; };
+__device__ __forceinline__ void arg_fold_min(float& v, int64_t& i, float ov, int64_t oi) {
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void arg_fold_max(float& v, int64_t& i, float ov, int64_t oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void block_argminmax(float& mnv, int64_t& mni, float& mxv, int64_t& mxi, float* sv,
+                                                int64_t* si) {
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        arg_fold_min(mnv, mni, __shfl_xor(mnv, s), __shfl_xor((long long)mni, s));
+        arg_fold_max(mxv, mxi, __shfl_xor(mxv, s), __shfl_xor((long long)mxi, s));
+    }
+    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6;
+    if (nw > 1) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { sv[w] = mnv; si[w] = mni; sv[16 + w] = mxv; si[16 + w] = mxi; }
+        __syncthreads();
+        mnv = sv[0]; mni = si[0]; mxv = sv[16]; mxi = si[16];
+        for (int j = 1; j < nw; ++j) {
+            arg_fold_min(mnv, mni, sv[j], si[j]);
+            arg_fold_max(mxv, mxi, sv[16 + j], si[16 + j]);
+        }
+    }
+}
+// grid = nb * chunks blocks; chunk c of bucket b scans its slice; chunks == 1 writes the result
+// directly, otherwise partial pairs go to `pv/pi` ([2*chunks] each) for k_arg_final.
+__global__ __launch_bounds__(256) void k_argminmax(const float* x, int64_t n, int64_t row, int64_t nb, int chunks,
+                                                   const float* mean, float me, int64_t* argmin, int64_t* argmax,
+                                                   float* pv, int64_t* pi) {
+    __shared__ float sv[32];
+    __shared__ int64_t si[32];
+    Prep pp;
+    pp.mean = mean ? *mean : 0.0f;
+    pp.me = me;
+    for (int64_t w = blockIdx.x; w < nb * chunks; w += gridDim.x) {
+        const int64_t bkt = w / chunks;
+        const int c = (int)(w % chunks);
+        const int64_t lo = bkt * row;
+        const int64_t hi = lo + row < n ? lo + row : n;
+        const int64_t len = hi - lo;
+        const int64_t per = (len + chunks - 1) / chunks;
+        const int64_t clo = lo + c * per;
+        const int64_t chi = clo + per < hi ? clo + per : hi;
+        float mnv = INFINITY, mxv = -INFINITY;
+        int64_t mni = INT64_MAX, mxi = INT64_MAX;
+        for (int64_t i = clo + threadIdx.x; i < chi; i += blockDim.x) {
+            const float v = prep(x[i], pp);
+            if (mni == INT64_MAX || v < mnv) { mnv = v; mni = i - lo; }   // strict: first occurrence wins
+            if (mxi == INT64_MAX || v > mxv) { mxv = v; mxi = i - lo; }
+        }
+        block_argminmax(mnv, mni, mxv, mxi, sv, si);
+        if (threadIdx.x == 0) {
+            if (chunks == 1) { argmin[bkt] = mni; argmax[bkt] = mxi; }
+            else { pv[c] = mnv; pi[c] = mni; pv[chunks + c] = mxv; pi[chunks + c] = mxi; }
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_arg_final(const float* pv, const int64_t* pi, int chunks, int64_t* argmin,
+                                                   int64_t* argmax) {
+    __shared__ float sv[32];
+    __shared__ int64_t si[32];
+    float mnv = INFINITY, mxv = -INFINITY;
+    int64_t mni = INT64_MAX, mxi = INT64_MAX;
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+        if (pi[c] != INT64_MAX) arg_fold_min(mnv, mni, pv[c], pi[c]);
+        if (pi[chunks + c] != INT64_MAX) arg_fold_max(mxv, mxi, pv[chunks + c], pi[chunks + c]);
+    }
+    block_argminmax(mnv, mni, mxv, mxi, sv, si);
+    if (threadIdx.x == 0) { argmin[0] = mni; argmax[0] = mxi; }
+}
+
+// ---- K6: point gradient (quant_functions.py:493-503) ------------------------------------------
+// stage 1: every block accumulates sum_{idx==j} g*alpha over its slice into k bins.
+// KR > 0: bins live in registers (k <= KR, fully unrolled select-accumulate, deterministic);
+// KR == 0: bins live in LDS, one private set per wave (k <= kMaxPoints).
+template <int KR>
+__global__ __launch_bounds__(256) void k_point_grad_partial(const float* g, const void* idx, int idx_bytes,
+                                                            const float* alpha, int64_t n, int64_t row, int64_t nb,
+                                                            int k, float* part /* [grid][k] */) {
+    __shared__ float bins[KR > 0 ? 4 * 16 : 4 * kMaxPoints];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int stride = KR > 0 ? 16 : kMaxPoints;
+    if (KR > 0) {
+        float acc[KR > 0 ? KR : 1];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) acc[j] = 0.0f;
+        for (int64_t i = tid; i < n; i += nth) {
+            const int64_t bkt = nb == 1 ? 0 : i / row;
+            const float m = g[i] * alpha[bkt];       // one fp32 multiply, :495
+            const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) acc[j] += (id == j) ? m : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const float s = wave_sum(acc[j]);
+            if (lane == 0) bins[w * stride + j] = s;
+        }
+    } else {
+        for (int j = lane; j < k; j += 64) bins[w * stride + j] = 0.0f;
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += nth) {
+            const int64_t bkt = nb == 1 ? 0 : i / row;
+            const float m = g[i] * alpha[bkt];
+            const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
+            atomicAdd(&bins[w * stride + id], m);    // LDS atomic, wave-private bins
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x)
+        part[(int64_t)blockIdx.x * k + j] =
+            (bins[j] + bins[stride + j]) + (bins[2 * stride + j] + bins[3 * stride + j]);
+}
+// stage 2: fixed-order fold of the per-block partials, float64 accumulation
+__global__ __launch_bounds__(256) void k_point_grad_final(const float* part, int nblocks, int k, float* out) {
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        double acc = 0.0;
+        for (int b = 0; b < nblocks; ++b) acc += (double)part[(int64_t)b * k + j];
+        out[j] = (float)acc;
+    }
+}
+
+// ---- K7: 'complicated' STE backward, one wave per bucket --------------------------------------
+__global__ __launch_bounds__(256) void k_ste_backward(const float* x, const float* g, float* out, int64_t n,
+                                                      int64_t row, int64_t nb, float sm1, int tie_mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t bkt = wave; bkt < nb; bkt += nwaves) {
+        const int64_t lo = bkt * row;
+        const int64_t hi = lo + row < n ? lo + row : n;
+        // pass 1: alpha/beta of x
+        float mn = INFINITY, mx = -INFINITY;
+        for (int64_t i = lo + lane; i < hi; i += 64) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        mn = wave_min(mn); mx = wave_max(mx);
+        float a, b;
+        alpha_beta(mn, mx, a, b);
+        // pass 2: min/max of the QUANTIZED bucket (the reference re-runs scale_down on q, :350)
+        float qmn = INFINITY, qmx = -INFINITY;
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            float lev;
+            const float q = qdq(x[i], a, b, sm1, 0.0f, lev);
+            qmn = fminf(qmn, q); qmx = fmaxf(qmx, q);
+        }
+        qmn = wave_min(qmn); qmx = wave_max(qmx);
+        float aq, bq;
+        alpha_beta(qmn, qmx, aq, bq);
+        // pass 3: S_b and the first index at the top / bottom level (or the true arg of x)
+        float s = 0.0f;
+        long long jmax = INT64_MAX, jmin = INT64_MAX;
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            float lev;
+            const float xv = x[i];
+            const float q = qdq(xv, a, b, sm1, 0.0f, lev);
+            float qs = q - bq;  qs = qs / aq;
+            float u = xv - bq;  u = u / aq;              // (tensor-beta)/alpha with the re-derived pair, :400
+            const float d = qs - u;
+            s += g[i] * d;
+            const bool top = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmx) : (xv == mx);
+            const bool bot = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmn) : (xv == mn);
+            if (top && (long long)i < jmax) jmax = i;
+            if (bot && (long long)i < jmin) jmin = i;
+        }
+        s = wave_sum(s);
+        jmax = wave_min_ll(jmax);
+        jmin = wave_min_ll(jmin);
+        // pass 4: out = g, +S at jmax, -S at jmin (they cancel when the bucket is constant)
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            float o = g[i];
+            if (jmax != jmin) {
+                if (i == jmax) o = o + s;
+                if (i == jmin) o = o - s;
+            }
+            out[i] = o;
+        }
+    }
+}
+
+// ---- K8: 'truncated' STE ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_clamp(float* w, int64_t n, float limit) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < n; i += nth) {
+        float v = w[i];
+        v = v > limit ? limit : v;
+        v = v < -limit ? -limit : v;
+        w[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_truncated_ste(const float* w, float* grad, int64_t n, float limit) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < n; i += nth)
+        if (fabsf(w[i]) > limit) grad[i] = 0.0f;
+}
+
+// ---- multi-tensor K1: one launch for every parameter of a model -------------------------------
+// A tile = 4 buckets of one tensor = one wave iteration; a DPP row owns a bucket.  Full, 16-byte
+// aligned 256-element buckets take the register path, everything else the row16 scalar path.
+template <int ROW>
+__global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* table, int ntensors, int64_t total_tiles,
+                                                       int64_t bucket, float sm1) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane >> 4, l = lane & 15;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    Prep pp;
+    pp.mean = 0.0f;
+    pp.me = INFINITY;
+    for (int64_t t = wave; t < total_tiles; t += nwaves) {
+        int lo_t = 0, hi_t = ntensors - 1;               // last tensor with first_tile <= t
+        while (lo_t < hi_t) {
+            const int mid = (lo_t + hi_t + 1) >> 1;
+            if (table[mid].first_tile <= t) lo_t = mid; else hi_t = mid - 1;
+        }
+        const QdTensorDesc d = table[lo_t];
+        KParams p;
+        p.x = d.x; p.out = d.q; p.n = d.n;
+        p.row = d.n < bucket ? d.n : bucket;
+        p.nb = (d.n + p.row - 1) / p.row;
+        p.alpha = nullptr; p.beta = nullptr; p.mean = nullptr; p.me = INFINITY; p.sm1 = sm1; p.lev8 = nullptr;
+        p.idx = nullptr; p.idx_bytes = 0; p.pts = nullptr; p.k = 0; p.assign_mode = 0; p.prescaled = 0;
+        p.stochastic = 0; p.seed = 0; p.nvec = 0;
+        const int64_t bkt = (t - d.first_tile) * 4 + sub;
+        if (bkt >= p.nb) continue;
+        const int64_t lo = bkt * p.row;
+        const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+        const bool fast = ROW > 0 && (hi - lo) == ROW && p.row == ROW &&
+                          (((((uintptr_t)d.x) | ((uintptr_t)d.q)) & 15) == 0);
+        if (fast) {
+            constexpr int V = ROW > 0 ? ROW / 64 : 1;
+            const f4* src = (const f4*)(p.x + lo) + l;
+            f4 v[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = src[j * 16];
+            float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
+            float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+#pragma unroll
+            for (int j = 1; j < V; ++j) {
+                mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
+                mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+            }
+            mn = row16_min(mn); mx = row16_max(mx);
+            float a, b, lev;
+            alpha_beta(mn, mx, a, b);
+            f4* dst = (f4*)(p.out + lo) + l;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                f4 r;
+                r.x = qdq(v[j].x, a, b, sm1, 0.0f, lev);
+                r.y = qdq(v[j].y, a, b, sm1, 0.0f, lev);
+                r.z = qdq(v[j].z, a, b, sm1, 0.0f, lev);
+                r.w = qdq(v[j].w, a, b, sm1, 0.0f, lev);
+                dst[j * 16] = r;
+            }
+        } else {
+            bucket_row16<MODE_QDQ>(p, nullptr, bkt, lo, hi, l, pp);
+        }
+    }
+}
+
+// ================================ host side ====================================================
+
+struct Workspace {           // fixed carve-up of the caller's scratch buffer
+    float* minmax_part;      // [2*kPartialBlocks]
+    float* ab;               // [2]
+    double* sum_part;        // [kPartialBlocks]
+    float* arg_pv;           // [2*kPartialBlocks]
+    int64_t* arg_pi;         // [2*kPartialBlocks]
+    float* pg_part;          // [kPartialBlocks * kMaxPoints]
+};
+constexpr size_t kWsBytes = 64 * 1024 + (size_t)kPartialBlocks * kMaxPoints * sizeof(float);
+
+bool carve(void* ws, size_t bytes, Workspace& w) {
+    if (!ws || bytes < kWsBytes || (((uintptr_t)ws) & 15)) return false;
+    char* p = (char*)ws;
+    w.minmax_part = (float*)p;               p += 2 * kPartialBlocks * sizeof(float);     // 8 KiB
+    w.ab = (float*)p;                        p += 64;
+    w.sum_part = (double*)p;                 p += kPartialBlocks * sizeof(double);        // 8 KiB
+    w.arg_pv = (float*)p;                    p += 2 * kPartialBlocks * sizeof(float);     // 8 KiB
+    w.arg_pi = (int64_t*)p;                  p += 2 * kPartialBlocks * sizeof(int64_t);   // 16 KiB
+    p = (char*)ws + 64 * 1024;
+    w.pg_part = (float*)p;
+    return true;
+}
+
+inline void geometry(int64_t n, int64_t bucket, int64_t& nb, int64_t& row) {
+    if (bucket <= 0 || n < bucket) { nb = 1; row = n; return; }
+    row = bucket;
+    nb = (n + bucket - 1) / bucket;
+}
+
+inline int grid_cap() {
+    // 256 CUs x 8 resident 256-thread blocks; QD_GRID_CAP overrides it (tuning experiments only)
+    const char* e = getenv("QD_GRID_CAP");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 256 * 8;
+}
+inline int blocks_for(int64_t items, int per_block) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    const int cap = grid_cap();
+    return (int)(b < cap ? b : cap);
+}
+
+inline int check_launch() {
+    const hipError_t e = hipGetLastError();
+    return (int)e;
+}
+
+// launch the bucketed transform for nb > 1 (or a short single bucket)
+template <int MODE>
+int launch_bucketed(KParams& p, hipStream_t st) {
+    const bool aligned = ((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) == 0 &&
+                         (MODE != MODE_NEAREST || p.idx == nullptr || p.idx_bytes != 8 || (((uintptr_t)p.idx) & 15) == 0) &&
+                         (MODE != MODE_QDQ || p.lev8 == nullptr || (((uintptr_t)p.lev8) & 3) == 0);
+    const int64_t nfull = p.n / p.row;                 // leading full buckets
+#define QD_VEC(LPB, V)                                                                        \
+    {                                                                                         \
+        p.nvec = nfull;                                                                       \
+        const int64_t tiles = (nfull + (64 / LPB) - 1) / (64 / LPB);                          \
+        const int blocks = blocks_for(tiles, 4) + 1; /* +1: the block that owns the tail */   \
+        hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V>), dim3(blocks), dim3(256), 0, st, p);  \
+        return check_launch();                                                                \
+    }
+    if (aligned && p.nb > 1) {
+        switch (p.row) {
+            case 64: QD_VEC(16, 1)
+            case 128: QD_VEC(16, 2)
+            case 256: QD_VEC(16, 4)
+            case 512: QD_VEC(64, 2)
+            case 1024: QD_VEC(64, 4)
+            case 2048: QD_VEC(64, 8)
+            default: break;
+        }
+    }
+#undef QD_VEC
+    p.nvec = 0;
+    const int threads = p.row <= 64 ? 64 : p.row <= 256 ? 128 : p.row <= 4096 ? 256 : 1024;
+    const int blocks = blocks_for(p.nb, 1);
+    hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(blocks), dim3(threads), 0, st, p);
+    return check_launch();
+}
+
+// single bucket spanning a large tensor: reduce -> finalize -> apply
+template <int MODE>
+int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int64_t kSmall = 16384;
+    if (p.n <= kSmall) {                               // one block does both passes, one launch
+        p.nvec = 0;
+        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(1), dim3(1024), 0, st, p);
+        return check_launch();
+    }
+    Workspace w;
+    if (!carve(ws, ws_bytes, w)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    const float* ab = nullptr;
+    if (MODE == MODE_NEAREST && p.prescaled) {
+        // alpha/beta are inputs: copy the pair into the scratch slot the apply kernel reads
+        (void)hipMemcpyAsync(w.ab, p.alpha, sizeof(float), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(w.ab + 1, p.beta, sizeof(float), hipMemcpyDeviceToDevice, st);
+        ab = w.ab;
+    } else {
+        int pb = blocks_for(p.n, 256 * 4 * 8);
+        if (pb > kPartialBlocks) pb = kPartialBlocks;
+        hipLaunchKernelGGL(k_minmax_partial, dim3(pb), dim3(256), 0, st, p.x, p.n, p.mean, p.me, w.minmax_part);
+        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, st, w.minmax_part, pb, w.ab, p.alpha, p.beta);
+        ab = w.ab;
+    }
+    const int blocks = blocks_for(p.n, 256 * 4 * 4);
+    hipLaunchKernelGGL((k_single_apply<MODE>), dim3(blocks), dim3(256), 0, st, p, ab);
+    return check_launch();
+}
+
+template <int MODE>
+int run_transform(KParams& p, int64_t bucket, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (p.n == 0) return 0;
+    geometry(p.n, bucket, p.nb, p.row);
+    if (p.nb == 1) return launch_single<MODE>(p, ws, ws_bytes, st);
+    return launch_bucketed<MODE>(p, st);
+}
+
+}  // namespace
+
+// ================================ C ABI ========================================================
+extern "C" {
+
+int qd_abi_version(void) { return 1; }
+const char* qd_target_arch(void) { return "gfx950"; }
+
+const char* qd_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case QD_ERR_INVALID_ARGUMENT: return "qd: invalid argument";
+        case QD_ERR_WORKSPACE_TOO_SMALL: return "qd: workspace missing, misaligned or smaller than qd_workspace_bytes()";
+        case QD_ERR_UNSUPPORTED: return "qd: unsupported configuration";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "qd: unknown error";
+    }
+}
+
+size_t qd_workspace_bytes(void) { return kWsBytes; }
+
+int64_t qd_num_buckets(int64_t n, int64_t bucket) {
+    int64_t nb, row;
+    geometry(n, bucket, nb, row);
+    return nb;
+}
+int64_t qd_padded_length(int64_t n, int64_t bucket) {
+    int64_t nb, row;
+    geometry(n, bucket, nb, row);
+    return nb * row;
+}
+
+int qd_mean_f32(const float* x, int64_t n, float* mean_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !mean_out || n <= 0) return QD_ERR_INVALID_ARGUMENT;
+    Workspace w;
+    if (!carve(workspace, workspace_bytes, w)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    int pb = blocks_for(n, 256 * 4 * 8);
+    if (pb > kPartialBlocks) pb = kPartialBlocks;
+    hipLaunchKernelGGL(k_sum_partial, dim3(pb), dim3(256), 0, st, x, n, w.sum_part);
+    hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(256), 0, st, w.sum_part, pb, n, mean_out);
+    return check_launch();
+}
+
+int qd_uniform_f32(const float* x, float* q, int64_t n, int64_t bucket, int levels, float* alpha, float* beta,
+                   uint8_t* level_idx, const float* mean, int clamp, float max_element, int stochastic,
+                   uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || levels < 2 || bucket < 0 || (n > 0 && (!x || !q))) return QD_ERR_INVALID_ARGUMENT;
+    if (level_idx && levels > 256) return QD_ERR_INVALID_ARGUMENT;
+    KParams p = {};
+    p.x = x; p.out = q; p.n = n; p.alpha = alpha; p.beta = beta; p.mean = mean;
+    p.me = clamp ? max_element : INFINITY;
+    p.sm1 = (float)(levels - 1);
+    p.lev8 = level_idx;
+    p.stochastic = stochastic; p.seed = seed;
+    return run_transform<MODE_QDQ>(p, bucket, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int qd_scale_down_f32(const float* x, float* u, int64_t n, int64_t bucket, float* alpha, float* beta,
+                      const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (n < 0 || bucket < 0 || (n > 0 && (!x || !u || !alpha || !beta))) return QD_ERR_INVALID_ARGUMENT;
+    KParams p = {};
+    p.x = x; p.out = u; p.n = n; p.alpha = alpha; p.beta = beta; p.mean = mean;
+    p.me = clamp ? max_element : INFINITY;
+    return run_transform<MODE_SCALE>(p, bucket, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int qd_inv_scale_f32(const float* u, float* y, int64_t n, int64_t bucket, const float* alpha, const float* beta,
+                     const float* mean, void* stream) {
+    if (n < 0 || bucket < 0 || (n > 0 && (!u || !y || !alpha || !beta))) return QD_ERR_INVALID_ARGUMENT;
+    if (n == 0) return 0;
+    int64_t nb, row;
+    geometry(n, bucket, nb, row);
+    const int blocks = blocks_for(n, 256 * 4 * 4);
+    hipLaunchKernelGGL(k_inv_scale, dim3(blocks), dim3(256), 0, (hipStream_t)stream, u, y, n, row, nb, alpha, beta,
+                       mean);
+    return check_launch();
+}
+
+int qd_bucket_argminmax_f32(const float* x, int64_t n, int64_t bucket, const float* mean, int clamp,
+                            float max_element, int64_t* argmin, int64_t* argmax, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    if (n <= 0 || bucket < 0 || !x || !argmin || !argmax) return QD_ERR_INVALID_ARGUMENT;
+    int64_t nb, row;
+    geometry(n, bucket, nb, row);
+    hipStream_t st = (hipStream_t)stream;
+    const float me = clamp ? max_element : INFINITY;
+    int chunks = 1;
+    if (nb == 1 && n > 65536) {
+        chunks = (int)((n + 65535) / 65536);
+        if (chunks > kPartialBlocks) chunks = kPartialBlocks;
+    }
+    Workspace w = {};
+    if (chunks > 1 && !carve(workspace, workspace_bytes, w)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    const int threads = row <= 64 ? 64 : 256;
+    const int blocks = blocks_for(nb * chunks, 1);
+    hipLaunchKernelGGL(k_argminmax, dim3(blocks), dim3(threads), 0, st, x, n, row, nb, chunks, mean, me, argmin,
+                       argmax, w.arg_pv, w.arg_pi);
+    if (chunks > 1) hipLaunchKernelGGL(k_arg_final, dim3(1), dim3(256), 0, st, w.arg_pv, w.arg_pi, chunks, argmin, argmax);
+    return check_launch();
+}
+
+int qd_nearest_point_f32(const float* x, int prescaled, const float* points, int k, int assign_mode, float* q,
+                         void* idx, int idx_bytes, int64_t n, int64_t bucket, float* alpha, float* beta,
+                         const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    if (n < 0 || bucket < 0 || k < 1 || k > kMaxPoints || !points || (n > 0 && (!x || !q)))
+        return QD_ERR_INVALID_ARGUMENT;
+    if (idx && idx_bytes != 8 && idx_bytes != 1) return QD_ERR_INVALID_ARGUMENT;
+    if (idx && idx_bytes == 1 && k > 256) return QD_ERR_INVALID_ARGUMENT;
+    if (assign_mode != QD_ASSIGN_DISTANCE && assign_mode != QD_ASSIGN_MIDPOINT) return QD_ERR_INVALID_ARGUMENT;
+    if (prescaled && (!alpha || !beta)) return QD_ERR_INVALID_ARGUMENT;
+    KParams p = {};
+    p.x = x; p.out = q; p.n = n; p.alpha = alpha; p.beta = beta; p.mean = mean;
+    p.me = clamp ? max_element : INFINITY;
+    p.idx = idx; p.idx_bytes = idx_bytes; p.pts = points; p.k = k; p.assign_mode = assign_mode;
+    p.prescaled = prescaled ? 1 : 0;
+    return run_transform<MODE_NEAREST>(p, bucket, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const float* alpha, int64_t n, int64_t bucket,
+                      int k, float* grad_points, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || bucket < 0 || k < 1 || k > kMaxPoints || !grad_points || (n > 0 && (!g || !idx || !alpha)))
+        return QD_ERR_INVALID_ARGUMENT;
+    if (idx_bytes != 8 && idx_bytes != 1) return QD_ERR_INVALID_ARGUMENT;
+    Workspace w;
+    if (!carve(workspace, workspace_bytes, w)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t nb, row;
+    geometry(n > 0 ? n : 1, bucket, nb, row);
+    int blocks = blocks_for(n, 256 * 8);
+    if (blocks > kPartialBlocks) blocks = kPartialBlocks;
+#define QD_PG(KR) hipLaunchKernelGGL((k_point_grad_partial<KR>), dim3(blocks), dim3(256), 0, st, g, idx, idx_bytes, \
+                                     alpha, n, row, nb, k, w.pg_part)
+    if (k <= 4) QD_PG(4);
+    else if (k <= 8) QD_PG(8);
+    else if (k <= 16) QD_PG(16);
+    else QD_PG(0);
+#undef QD_PG
+    hipLaunchKernelGGL(k_point_grad_final, dim3(1), dim3(256), 0, st, w.pg_part, blocks, k, grad_points);
+    return check_launch();
+}
+
+int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64_t n, int64_t bucket, int levels,
+                               int tie_mode, void* stream) {
+    if (n < 0 || bucket <= 0 || levels < 2 || (n > 0 && (!x || !g || !out))) return QD_ERR_INVALID_ARGUMENT;
+    if (tie_mode != QD_STE_TIE_REFERENCE && tie_mode != QD_STE_TIE_TRUE_ARG) return QD_ERR_INVALID_ARGUMENT;
+    if (n == 0) return 0;
+    int64_t nb, row;
+    geometry(n, bucket, nb, row);
+    const int blocks = blocks_for(nb, 4);
+    hipLaunchKernelGGL(k_ste_backward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, g, out, n, row, nb,
+                       (float)(levels - 1), tie_mode);
+    return check_launch();
+}
+
+int qd_clamp_f32(float* w, int64_t n, float limit, void* stream) {
+    if (n < 0 || (n > 0 && !w)) return QD_ERR_INVALID_ARGUMENT;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_clamp, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, w, n, limit);
+    return check_launch();
+}
+
+int qd_truncated_ste_f32(const float* w, float* grad, int64_t n, float limit, void* stream) {
+    if (n < 0 || (n > 0 && (!w || !grad))) return QD_ERR_INVALID_ARGUMENT;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_truncated_ste, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, w, grad, n,
+                       limit);
+    return check_launch();
+}
+
+int64_t qd_multi_plan(QdTensorDesc* host_table, int ntensors, int64_t bucket) {
+    if (!host_table || ntensors < 0 || bucket <= 0) return -1;
+    int64_t tiles = 0;
+    for (int i = 0; i < ntensors; ++i) {
+        int64_t nb, row;
+        geometry(host_table[i].n > 0 ? host_table[i].n : 1, bucket, nb, row);
+        host_table[i].first_tile = tiles;
+        tiles += host_table[i].n > 0 ? (nb + 3) / 4 : 0;
+    }
+    return tiles;
+}
+
+int qd_multi_uniform_f32(const QdTensorDesc* table, int ntensors, int64_t total_tiles, int64_t bucket, int levels,
+                         void* stream) {
+    if (!table || ntensors <= 0 || total_tiles < 0 || bucket <= 0 || levels < 2) return QD_ERR_INVALID_ARGUMENT;
+    if (total_tiles == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = blocks_for(total_tiles, 4);
+    const float sm1 = (float)(levels - 1);
+    if (bucket == 256)
+        hipLaunchKernelGGL((k_multi_uniform<256>), dim3(blocks), dim3(256), 0, st, table, ntensors, total_tiles, bucket, sm1);
+    else if (bucket == 128)
+        hipLaunchKernelGGL((k_multi_uniform<128>), dim3(blocks), dim3(256), 0, st, table, ntensors, total_tiles, bucket, sm1);
+    else if (bucket == 64)
+        hipLaunchKernelGGL((k_multi_uniform<64>), dim3(blocks), dim3(256), 0, st, table, ntensors, total_tiles, bucket, sm1);
+    else
+        hipLaunchKernelGGL((k_multi_uniform<0>), dim3(blocks), dim3(256), 0, st, table, ntensors, total_tiles, bucket, sm1);
+    return check_launch();
+}
+
+}  // extern "C"

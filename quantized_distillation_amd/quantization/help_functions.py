@@ -1,0 +1,136 @@
+"""Host-side helpers of the quantizer (mirror of the reference's quantization/help_functions.py,
+cited as `ref:`).  These run off the per-step path: bucket reshaping for callers that want the
+view, the percentile initialisation of the quantization points, the bit-allocation heuristic
+and the Huffman size accounting.  The per-tensor work they need (scaling, assignment) goes
+through the HIP kernels; what remains on the host is what the reference also does on the host
+(np.percentile, a heap, a dict of frequencies).
+"""
+import math  # noqa: F401  (kept for API parity with the reference module namespace)
+from collections import defaultdict
+from heapq import heapify, heappop, heappush
+
+import numpy as np
+import torch
+
+
+def create_bucket_tensor(tensor, bucket_size, fill_values='last'):
+    """View `tensor` as rows of `bucket_size` elements, padding a ragged tail with copies of the
+    last element (or NaN).  ref: help_functions.py:67-94.  The kernels never materialise this
+    view (padding cannot change a bucket's min/max); it is provided for API compatibility."""
+    if bucket_size is None:
+        return tensor
+    flat = tensor.reshape(-1)
+    n = flat.numel()
+    if fill_values == 'nan':
+        fill = float('nan')
+    elif fill_values == 'last':
+        fill = flat[-1]
+    else:
+        fill = fill_values
+    full, rest = divmod(n, bucket_size)
+    if full == 0:
+        return flat.view(1, n)
+    if rest != 0:
+        pad = torch.empty(bucket_size - rest, dtype=flat.dtype, device=flat.device)
+        pad.fill_(fill) if not isinstance(fill, torch.Tensor) else pad.copy_(fill.expand_as(pad))
+        flat = torch.cat([flat, pad])
+    return flat.view(-1, bucket_size)
+
+
+def assign_bits_automatically(gradient_norms, inital_bits_to_assign, input_is_point=False):
+    """Redistribute a bit (or point) budget across tensors proportionally to their gradient
+    norms, keeping the total fixed.  ref: help_functions.py:97-138.  Pure host arithmetic."""
+    if isinstance(inital_bits_to_assign, int):
+        inital_bits_to_assign = [inital_bits_to_assign] * len(gradient_norms)
+    if len(inital_bits_to_assign) != len(gradient_norms):
+        raise ValueError('There should be as many gradients as there are initial points.')
+    gradient_norms = [float(g) for g in gradient_norms]     # accepts 0-dim device tensors
+    budget = sum(inital_bits_to_assign)
+    floor_alloc = [(b // 2) if input_is_point else (b - 1) for b in inital_bits_to_assign]
+    spare = budget - sum(floor_alloc)
+    norm_total = sum(gradient_norms)
+    alloc = [base + round(g / norm_total * spare) for g, base in zip(gradient_norms, floor_alloc)]
+    excess = sum(alloc) - budget
+    if excess > 0:
+        alloc[alloc.index(max(alloc))] -= excess
+    elif excess < 0:
+        alloc[alloc.index(min(alloc))] += -excess
+    return alloc
+
+
+def initialize_quantization_points(tensor, scaling_function, num_points):
+    """Starting points for the non-uniform optimisation: the `num_points` evenly spaced
+    percentiles of the scaled tensor.  ref: help_functions.py:140-154.  The scaling runs on the
+    device (K2); the percentile itself is the reference's host-side np.percentile (setup path,
+    once per tensor)."""
+    scaled = scaling_function.scale_down(tensor).view(-1)[0:scaling_function.original_tensor_length]
+    values = np.percentile(scaled.cpu().numpy(), np.linspace(0, 100, num=num_points))
+    return torch.from_numpy(values).type_as(tensor).to(tensor.device)
+
+
+def huffman_encode(symb2freq):
+    """Huffman code of a {symbol: weight} dict as a list of [symbol, code] sorted by code length.
+    ref: help_functions.py:157-172."""
+    heap = [[weight, [symbol, '']] for symbol, weight in symb2freq.items()]
+    heapify(heap)
+    while len(heap) > 1:
+        low, high = heappop(heap), heappop(heap)
+        for entry in low[1:]:
+            entry[1] = '0' + entry[1]
+        for entry in high[1:]:
+            entry[1] = '1' + entry[1]
+        heappush(heap, [low[0] + high[0]] + low[1:] + high[1:])
+    return sorted(heappop(heap)[1:], key=lambda e: (len(e[-1]), e))
+
+
+def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_functions, type_quantization='uniform',
+                                         s=None):
+    """Mean Huffman code length (bits/weight) of the quantization indices of a model.
+    ref: help_functions.py:175-232."""
+    type_quantization = type_quantization.lower()
+    if type_quantization not in ('uniform', 'nonuniform'):
+        raise ValueError('type_quantization not recognized')
+    if s is None and type_quantization == 'uniform':
+        raise ValueError('If type of quantization is uniform, you must provide s')
+    if not isinstance(quantization_functions, list):
+        quantization_functions = [quantization_functions]
+    shared = len(quantization_functions) == 1
+    counts = defaultdict(int)
+    total = 0
+    tol = 1e-5
+    for pos, param in enumerate(model_param_iter):
+        param = param.clone()
+        if hasattr(param, 'data'):
+            param = param.data
+        total += param.numel()
+        fn = quantization_functions[0] if shared else quantization_functions[pos]
+        if type_quantization == 'uniform':
+            q_tensor, scal = fn(param)
+            scaled = scal.scale_down(q_tensor).view(-1)[0:scal.original_tensor_length].cpu().numpy()
+            edges = [x / (s - 1) - tol for x in range(s)]
+            bins = np.digitize(scaled, edges).flatten() - 1
+        else:
+            _, bins, _ = fn(param)
+            bins = bins.view(-1).cpu().numpy()
+        for value, count in zip(*np.unique(bins, return_counts=True)):
+            counts[value] += count
+    assert total == sum(counts.values())
+    freq = {sym: c / total for sym, c in counts.items()}
+    return sum(freq[sym] * len(code) for sym, code in huffman_encode(freq))
+
+
+def check_right_bits(tensor_iterator, num_quant_points, bucket_size):
+    """True if no tensor has (many) more distinct scaled values than quantization points.
+    ref: help_functions.py:234-262 (which notes itself that the check is approximate)."""
+    from .quant_functions import ScalingFunction
+    per_tensor = not isinstance(num_quant_points, int)
+    scaling_function = ScalingFunction('linear', False, False, bucket_size=bucket_size)
+    for pos, tensor in enumerate(tensor_iterator):
+        if hasattr(tensor, 'data'):
+            tensor = tensor.data
+        scaled = scaling_function.scale_down(tensor)
+        distinct = len(np.unique(scaled.view(-1).cpu().numpy().round(decimals=5)))
+        limit = num_quant_points[pos] if per_tensor else num_quant_points
+        if distinct > limit + 3:
+            return False
+    return True

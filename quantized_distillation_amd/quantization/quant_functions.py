@@ -1,0 +1,493 @@
+"""Host-side mirror of the reference's quantization/quant_functions.py on top of libqd_hip.so.
+
+Same public names, argument meaning, return tuples and exceptions as the reference
+(antspy/quantized_distillation, quantization/quant_functions.py -- cited as `ref:` below), so that
+`train_model(..., quantizeWeights=True)` (cnn_models/conv_forward_model.py:165-393,
+translation_models/model.py:161-317) and `optimize_quantization_points` (:395-592 / :319-442)
+can call it unchanged.  What differs is *how* it runs: each call is one (at most three) HIP
+kernel launches through the C ABI of include/qd_hip.h instead of ~12 unfused torch ops, there
+is no host synchronisation and no device<->host round trip anywhere on the per-step path.
+
+Tensors must be float32 and live on a HIP device; there is no CPU path in this package.
+"""
+import numbers
+
+import torch
+
+from .. import _lib
+
+_STOCHASTIC_CALLS = [0]
+
+
+def _bucket_arg(bucket_size):
+    return 0 if bucket_size is None else int(bucket_size)
+
+
+def _geometry(n, bucket_size):
+    """(num_buckets, row_length) of the bucket view; ref: help_functions.py:67-94."""
+    if bucket_size is None or n < bucket_size:
+        return 1, n
+    return -(-n // bucket_size), bucket_size
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class ScalingFunction(object):
+    """Scaling of a tensor to [0,1] and its inverse (ref: quant_functions.py:7-152).
+
+    Holds what the inverse needs: `alpha`, `beta` (per bucket, shape (nb, 1); shape (1,) without
+    buckets), `mean_tensor`, `original_tensor_size`, `original_tensor_length`,
+    `expected_tensor_size`.  `idx_min_rows` / `idx_max_rows` (first-occurrence arg-min/max per
+    bucket, int64) are computed ON DEMAND from the retained input the first time they are read:
+    nothing on the per-step path reads them, and materialising them eagerly as the reference
+    does (:85-90) would add 16 B/bucket of traffic plus index tracking to the hot kernel.  They
+    are therefore only valid while the tensor passed to `scale_down` has not been modified
+    (with `modify_in_place=True` they are computed eagerly, before the data is overwritten).
+    """
+
+    def __init__(self, type_scaling, max_element, subtract_mean, bucket_size, modify_in_place=False):
+        type_scaling = type_scaling.lower()
+        if type_scaling not in ('linear', 'absmax', 'absnorm'):                     # ref: :22-25
+            raise ValueError('Incorrect parameter: type of scaling must be "linear", "absMax" or "absNorm"')
+        if bucket_size is not None and (not isinstance(bucket_size, int) or isinstance(bucket_size, bool)
+                                        or bucket_size <= 0):                       # ref: :27-29
+            raise ValueError('Bucket size must be an integer and strictly positive. '
+                             'Pass None if you want to avoid using buckets')
+        if max_element is True:                                                     # ref: :31-33
+            raise ValueError('maxElementAllowed must be a number')
+        if max_element is not False and not isinstance(max_element, numbers.Number):
+            raise ValueError('maxElementAllowed must be a number')
+
+        self.type_scaling = type_scaling
+        self.max_element = max_element
+        self.subtract_mean = subtract_mean
+        self.bucket_size = bucket_size
+        self.modify_in_place = modify_in_place
+        self.tol_diff_zero = 1e-10
+
+        self.mean_tensor = None
+        self.original_tensor_size = None
+        self.original_tensor_length = None
+        self.expected_tensor_size = None
+        self.alpha = None
+        self.beta = None
+        self.norm_scaling = None
+        self.tensor_sign = None
+        self._idx_min_rows = None
+        self._idx_max_rows = None
+        self._arg_source = None        # (tensor, mean_buf) kept for the lazy arg-min/max
+        self._mean_buf = None
+
+    # ------------------------------------------------------------------ helpers
+    def _require_linear(self):
+        if self.type_scaling != 'linear':
+            # ref: :109-127 raises on every torch version (tensor.max(p=2, ...) is not a valid call
+            # and :126 stores a bound method), so there is no behaviour to be compatible with.
+            raise NotImplementedError(
+                "type_scaling '%s' is not available: the reference implementation of absmax/absnorm "
+                "(quant_functions.py:109-127) raises on every torch version; only 'linear' is defined"
+                % self.type_scaling)
+
+    def _clamp_args(self):
+        if self.max_element is False:
+            return 0, 0.0
+        return 1, float(self.max_element)
+
+    def _begin(self, tensor):
+        """Record sizes, compute the mean if requested; returns (flat contiguous tensor, n, nb, row)."""
+        _lib.require_device_f32(tensor)
+        self._require_linear()
+        if not tensor.is_contiguous():
+            if self.modify_in_place:
+                raise ValueError('modify_in_place=True needs a contiguous tensor')
+            tensor = tensor.contiguous()
+        n = tensor.numel()
+        self.original_tensor_size = tensor.size()
+        self.original_tensor_length = n
+        nb, row = _geometry(n, self.bucket_size)
+        if self.bucket_size is None:
+            self.expected_tensor_size = torch.Size([n])                              # ref: :79-81
+        else:
+            self.expected_tensor_size = torch.Size([nb, row])
+        if self.subtract_mean:
+            self._mean_buf = torch.empty(1, dtype=torch.float32, device=tensor.device)
+            if n > 0:
+                ws = _lib.workspace(tensor.device)
+                _lib.check(_lib.load().qd_mean_f32(tensor.data_ptr(), n, self._mean_buf.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+            self.mean_tensor = self._mean_buf.view(())                               # 0-dim, ref: :67
+        else:
+            self._mean_buf = None
+            self.mean_tensor = 0                                                     # ref: :70
+        return tensor, n, nb, row
+
+    def _alloc_alpha_beta(self, nb, device):
+        ab = torch.empty(2, nb, dtype=torch.float32, device=device)
+        shape = (1,) if self.bucket_size is None else (nb, 1)
+        self.alpha = ab[0].view(*shape)
+        self.beta = ab[1].view(*shape)
+        return ab
+
+    def _note_arg_source(self, tensor, overwritten):
+        self._idx_min_rows = None
+        self._idx_max_rows = None
+        self._arg_source = tensor
+        if overwritten:                # the data is about to be replaced: materialise now
+            self._compute_arg_indices()
+
+    def _compute_arg_indices(self):
+        t = self._arg_source
+        if t is None:
+            return
+        n = t.numel()
+        nb, _ = _geometry(n, self.bucket_size)
+        out = torch.empty(2, nb, dtype=torch.int64, device=t.device)
+        clamp, me = self._clamp_args()
+        if n > 0:
+            ws = _lib.workspace(t.device)
+            _lib.check(_lib.load().qd_bucket_argminmax_f32(
+                t.data_ptr(), n, _bucket_arg(self.bucket_size), _ptr(self._mean_buf), clamp, me,
+                out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        shape = (1,) if self.bucket_size is None else (nb, 1)
+        self._idx_min_rows = out[0].view(*shape)
+        self._idx_max_rows = out[1].view(*shape)
+        self._arg_source = None
+
+    @property
+    def idx_min_rows(self):
+        if self._idx_min_rows is None:
+            self._compute_arg_indices()
+        return self._idx_min_rows
+
+    @idx_min_rows.setter
+    def idx_min_rows(self, v):
+        self._idx_min_rows = v
+
+    @property
+    def idx_max_rows(self):
+        if self._idx_max_rows is None:
+            self._compute_arg_indices()
+        return self._idx_max_rows
+
+    @idx_max_rows.setter
+    def idx_max_rows(self, v):
+        self._idx_max_rows = v
+
+    # ------------------------------------------------------------------ API
+    def scale_down(self, tensor):
+        """u = (x - beta)/alpha per bucket, returned in the bucket layout (nb, bucket) -- padded
+        with the scaled last element when the tensor is ragged -- or 1-D without buckets.
+        ref: :56-129.  One kernel (K2)."""
+        tensor, n, nb, row = self._begin(tensor)
+        padded = nb * row
+        in_place = self.modify_in_place and padded == n
+        self._note_arg_source(tensor, overwritten=in_place)
+        out = tensor.view(-1) if in_place else torch.empty(padded, dtype=torch.float32, device=tensor.device)
+        ab = self._alloc_alpha_beta(nb, tensor.device)
+        clamp, me = self._clamp_args()
+        if n > 0:
+            ws = _lib.workspace(tensor.device)
+            _lib.check(_lib.load().qd_scale_down_f32(
+                tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(self.bucket_size), ab[0].data_ptr(),
+                ab[1].data_ptr(), _ptr(self._mean_buf), clamp, me, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return out.view(self.expected_tensor_size)
+
+    def inv_scale_down(self, tensor):
+        """Inverse of scale_down (max_element truncation is not inverted).  ref: :131-152.  K3."""
+        _lib.require_device_f32(tensor)
+        self._require_linear()
+        if tensor.size() != self.expected_tensor_size:                               # ref: :138-139
+            raise ValueError('The tensor passed has not the expected size.')
+        if not tensor.is_contiguous():
+            tensor = tensor.contiguous()
+        n = self.original_tensor_length
+        out = tensor.view(-1)[0:n] if self.modify_in_place else torch.empty(n, dtype=torch.float32,
+                                                                          device=tensor.device)
+        if n > 0:
+            _lib.check(_lib.load().qd_inv_scale_f32(
+                tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(self.bucket_size), self.alpha.data_ptr(),
+                self.beta.data_ptr(), _ptr(self._mean_buf), _lib.stream_ptr()))
+        return out.view(self.original_tensor_size)
+
+
+def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding=False,
+                        max_element=False, subtract_mean=False, bucket_size=None, modify_in_place=False):
+    """k-level uniform quantize-dequantize ("fake quantization") of `tensor` with `s` levels.
+    Returns (quantized tensor of the same shape, ScalingFunction).  ref: :155-194.
+
+    One fused kernel (K1) for bucketed tensors -- per-bucket min/max, alpha/beta, scale, round
+    half to even, rescale; three small launches without buckets (global reduce, fold, apply).
+    The input is left untouched unless modify_in_place=True."""
+    scaling_function = ScalingFunction(type_of_scaling, max_element, subtract_mean, bucket_size,
+                                       modify_in_place=True)                         # as the reference, :166-167
+    saved_flag = modify_in_place
+    scaling_function.modify_in_place = modify_in_place      # governs _begin's contiguity rule
+    tensor, n, nb, row = scaling_function._begin(tensor)
+    scaling_function.modify_in_place = True
+    if int(s) != s or s < 2:
+        raise ValueError('s must be an integer >= 2')
+    scaling_function._note_arg_source(tensor, overwritten=saved_flag)
+    out = tensor if modify_in_place else torch.empty_like(tensor)
+    ab = scaling_function._alloc_alpha_beta(nb, tensor.device)
+    clamp, me = scaling_function._clamp_args()
+    seed = 0
+    if stochastic_rounding:
+        _STOCHASTIC_CALLS[0] += 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _STOCHASTIC_CALLS[0]) & 0xFFFFFFFFFFFFFFFF
+    if n > 0:
+        ws = _lib.workspace(tensor.device)
+        _lib.check(_lib.load().qd_uniform_f32(
+            tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), ab[0].data_ptr(),
+            ab[1].data_ptr(), None, _ptr(scaling_function._mean_buf), clamp, me, 1 if stochastic_rounding else 0,
+            seed, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    return out, scaling_function
+
+
+class SearchSorted:
+    """Device handle standing in for the reference's SearchSorted (ref: :509-573).
+
+    The reference sorts the scaled tensor on the CPU (two argsorts, 4x the tensor's memory) so
+    that each query is a searchsorted of the k-1 midpoints.  On the GPU none of that is needed:
+    the index of an element is simply #{midpoints <= u}, computed per element by K5.  This object
+    therefore only keeps `u` (fp32, device, unpadded order) resident between steps."""
+
+    def __init__(self, tensor, use_k_optimization=True):
+        _lib.require_device_f32(tensor, 'SearchSorted tensor')
+        self.scaled_tensor = tensor.contiguous().view(-1)
+        self.use_k_optimization = use_k_optimization
+
+    def query(self, k):
+        """Indices (int64, flat) of the nearest point of `k` (sorted 1-D points) for every
+        element, by the midpoint rule of ref: :531-563."""
+        pts = _points_on(k, self.scaled_tensor.device)
+        n = self.scaled_tensor.numel()
+        idx = torch.empty(n, dtype=torch.int64, device=self.scaled_tensor.device)
+        scratch = torch.empty(n, dtype=torch.float32, device=self.scaled_tensor.device)
+        one = torch.ones(1, dtype=torch.float32, device=pts.device)
+        zero = torch.zeros(1, dtype=torch.float32, device=pts.device)
+        ws = _lib.workspace(pts.device)
+        if n > 0:
+            _lib.check(_lib.load().qd_nearest_point_f32(
+                self.scaled_tensor.data_ptr(), 1, pts.data_ptr(), pts.numel(), 1, scratch.data_ptr(),
+                idx.data_ptr(), 8, n, 0, one.data_ptr(), zero.data_ptr(), None, 0, 0.0,
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        return idx
+
+
+def _points_on(points, device):
+    if isinstance(points, (list, tuple)):
+        points = torch.tensor(points, dtype=torch.float32)                            # ref: :238-239
+    if not isinstance(points, torch.Tensor):
+        points = torch.as_tensor(points, dtype=torch.float32)
+    points = points.detach()
+    if points.dtype != torch.float32 or points.device != device or not points.is_contiguous():
+        points = points.to(device=device, dtype=torch.float32).contiguous()
+    return points
+
+
+def _nearest(x_ptr, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mean_buf, clamp, me,
+             device, idx_bytes):
+    q = torch.empty(n, dtype=torch.float32, device=device)
+    idx = torch.empty(n, dtype=torch.int64 if idx_bytes == 8 else torch.uint8, device=device)
+    if n > 0:
+        ws = _lib.workspace(device)
+        _lib.check(_lib.load().qd_nearest_point_f32(
+            x_ptr, prescaled, points.data_ptr(), points.numel(), assign_mode, q.data_ptr(), idx.data_ptr(),
+            idx_bytes, n, _bucket_arg(bucket_size), alpha.data_ptr(), beta.data_ptr(), _ptr(mean_buf), clamp, me,
+            ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    return q, idx
+
+
+def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
+                           subtract_mean=False, modify_in_place=False, bucket_size=None,
+                           pre_processed_values=False, search_sorted_obj=None, scaling_function=None,
+                           tensors_info=None):
+    """Quantize every element to the nearest of the (sorted, in [0,1]) quantization points after
+    per-bucket linear scaling.  Returns (quantized, indices int64 of the same shape,
+    ScalingFunction).  ref: :196-290.
+
+    Plain path: one fused kernel (K4: scale, nearest point by the distance rule of :267-273,
+    gather, rescale).  Pre-processed path (`pre_processed_values=True`, the per-step call of
+    differentiable quantization): the scaled tensor stays resident on the device inside
+    `search_sorted_obj`, and one kernel (K5) assigns by the midpoint rule of :531-563."""
+    if pre_processed_values is True and (search_sorted_obj is None or scaling_function is None
+                                         or tensors_info is None):                  # ref: :230-231
+        raise ValueError('If values are preprocessed, all pre processed arguments need to be passed')
+    if pre_processed_values is False and not (search_sorted_obj is None and scaling_function is None
+                                              and tensors_info is None):              # ref: :233-236
+        raise ValueError('pre processing is False but you are passing some pre processing values. '
+                         'This is probably not what you wanted to do, so to avoid bugs an error is raised')
+
+    if not pre_processed_values:
+        sf = ScalingFunction(type_scaling='linear', max_element=max_element, subtract_mean=subtract_mean,
+                             bucket_size=bucket_size, modify_in_place=True)           # ref: :248-250
+        sf.modify_in_place = modify_in_place
+        tensor, n, nb, row = sf._begin(tensor)
+        sf.modify_in_place = True
+        sf._note_arg_source(tensor, overwritten=modify_in_place)
+        points = _points_on(listQuantizationPoints, tensor.device)
+        sf._alloc_alpha_beta(nb, tensor.device)
+        clamp, me = sf._clamp_args()
+        q, idx = _nearest(tensor.data_ptr(), 0, points, 0, n, bucket_size, sf.alpha, sf.beta, sf._mean_buf,
+                          clamp, me, tensor.device, 8)
+        if modify_in_place:
+            tensor.view(-1).copy_(q)
+            q = tensor
+        return q.view(sf.original_tensor_size), idx.view(sf.original_tensor_size), sf
+
+    sf = scaling_function
+    u = search_sorted_obj.scaled_tensor
+    n = sf.original_tensor_length
+    points = _points_on(listQuantizationPoints, u.device)
+    q, idx = _nearest(u.data_ptr(), 1, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf, 0, 0.0,
+                      u.device, 8)
+    return q.view(sf.original_tensor_size), idx.view(sf.original_tensor_size), sf
+
+
+class uniformQuantization_variable(object):
+    """Forward/backward pair around uniformQuantization, called as plain methods by the training
+    loops (cnn_models/conv_forward_model.py:245,266), not through autograd.  ref: :293-406.
+
+    `backward` is the 'complicated' straight-through estimator: one kernel (K7), one wave per
+    bucket, instead of the reference's N x N sparse matrices (which, as shipped, raise for more
+    than one bucket -- this implements the intended math with the reference's tie rule)."""
+
+    def __init__(self, s, type_of_scaling='linear', stochastic_rounding=False, max_element=False,
+                 subtract_mean=False, modify_in_place=False, bucket_size=None):
+        self.s = s
+        self.typeOfScaling = type_of_scaling
+        self.stochasticRounding = stochastic_rounding
+        self.maxElementAllowed = max_element
+        self.subtractMean = subtract_mean
+        self.modifyInPlace = modify_in_place
+        self.bucket_size = bucket_size
+        self.saved_for_backward = None
+
+    def forward(self, input):
+        self.saved_for_backward = {'input': input.clone()}                           # ref: :308-309
+        return uniformQuantization(input, s=self.s, type_of_scaling=self.typeOfScaling,
+                                   stochastic_rounding=self.stochasticRounding,
+                                   max_element=self.maxElementAllowed, subtract_mean=self.subtractMean,
+                                   modify_in_place=self.modifyInPlace, bucket_size=self.bucket_size)[0]
+
+    __call__ = forward
+
+    def backward(self, grad_output, tie_mode='reference'):
+        if self.typeOfScaling != 'linear':                                           # ref: :326-327
+            raise ValueError('Linear scaling is necessary to backpropagate')
+        if self.subtractMean is True:                                                # ref: :329-330
+            raise NotImplementedError('The backprop function assumes subtractMean to be False for now')
+        if self.bucket_size is None:                                                 # ref: :332-334
+            raise NotImplementedError('Right now the code does not work with bucket_size None.'
+                                      ' Not hard to modify though')
+        if self.saved_for_backward is None:                                          # ref: :336-337
+            raise ValueError('Need to have called .forward() to be able to call .backward()')
+        x = self.saved_for_backward['input']
+        _lib.require_device_f32(grad_output, 'grad_output')
+        g = grad_output.contiguous()
+        if g.numel() != x.numel():
+            raise ValueError('grad_output must have as many elements as the input of forward()')
+        out = torch.empty_like(g)
+        if x.numel() > 0:
+            _lib.check(_lib.load().qd_ste_bucket_backward_f32(
+                x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel(), int(self.bucket_size), int(self.s),
+                0 if tie_mode == 'reference' else 1, _lib.stream_ptr()))
+        self.saved_for_backward = None                                               # ref: :404-405
+        return out.view(x.size())
+
+
+class _Saved(dict):
+    """savedForBackward of nonUniformQuantization_variable.  The kernels keep the assignment as
+    uint8 when k <= 256 (1 B/element instead of 8); callers that read ['indices'] still get the
+    LongTensor the reference stores (converted on access)."""
+
+    def __getitem__(self, key):
+        if key == 'indices':
+            raw = dict.__getitem__(self, 'indices')
+            return raw if raw.dtype == torch.int64 else raw.long()
+        return dict.__getitem__(self, key)
+
+    def raw_indices(self):
+        return dict.__getitem__(self, 'indices')
+
+
+class nonUniformQuantization_variable(object):
+    """Forward/backward pair of non-uniform quantization used by the differentiable-quantization
+    loop (cnn_models/conv_forward_model.py:507-545).  ref: :408-506.
+
+    With `pre_process_tensors=True` the tensor is scaled ONCE (K2) and `u`, alpha, beta stay on
+    the device; every `forward(None, points)` is then a single kernel (K5) that reads u (4 B),
+    writes q (4 B) and a uint8 index (1 B) per element, and `backward` is a deterministic
+    two-stage segmented reduction (K6).  No sort, no host round trip (the reference moves N
+    int64 + N fp32 across PCIe per tensor per step, :279-284)."""
+
+    def __init__(self, max_element=False, subtract_mean=False, modify_in_place=False, bucket_size=None,
+                 pre_process_tensors=False, tensor=None):
+        if pre_process_tensors is True and (tensor is None):                          # ref: :413-414
+            raise ValueError('To pre-process tensors you need to pass the tensor and the scaling function options')
+        self.maxElementAllowed = max_element
+        self.subtractMean = subtract_mean
+        self.modifyInPlace = modify_in_place
+        self.bucket_size = bucket_size
+        self.savedForBackward = None
+        self.pre_process_tensors = pre_process_tensors
+        self.search_sorted_obj = None
+        self.tensors_info = None
+        self.scaling_function = None
+        if self.pre_process_tensors:
+            self.preprocess(tensor)
+
+    def preprocess(self, tensor):
+        sf = ScalingFunction(type_scaling='linear', max_element=self.maxElementAllowed,
+                             subtract_mean=self.subtractMean, bucket_size=self.bucket_size,
+                             modify_in_place=self.modifyInPlace)
+        u = sf.scale_down(tensor)                                                     # ref: :437
+        sf.modify_in_place = True
+        self.search_sorted_obj = SearchSorted(u.view(-1)[0:sf.original_tensor_length])
+        self.tensors_info = (tensor.type(), tensor.is_cuda)
+        self.scaling_function = sf
+
+    def forward(self, inputTensor, listQuantizationPoints):
+        if listQuantizationPoints.dim() != 1:                                         # ref: :451-452
+            raise ValueError('listPoints must be a 1-D tensor')
+        numPoints = listQuantizationPoints.size()[0]
+        if self.pre_process_tensors:
+            sf = self.scaling_function
+            u = self.search_sorted_obj.scaled_tensor
+            points = _points_on(listQuantizationPoints, u.device)
+            n = sf.original_tensor_length
+            q, idx = _nearest(u.data_ptr(), 1, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf,
+                              0, 0.0, u.device, 1 if numPoints <= 256 else 8)
+            q = q.view(sf.original_tensor_size)
+            idx = idx.view(sf.original_tensor_size)
+        else:
+            q, idx, sf = nonUniformQuantization(
+                inputTensor, listQuantizationPoints, modify_in_place=self.modifyInPlace,
+                max_element=self.maxElementAllowed, subtract_mean=self.subtractMean, bucket_size=self.bucket_size)
+        self.savedForBackward = _Saved(indices=idx, numPoints=numPoints, scalingFactor=sf.alpha)   # ref: :467-468
+        return q
+
+    __call__ = forward
+
+    def backward(self, grad_output):
+        """Returns (grad wrt the input = grad_output unchanged, grad wrt the points).  ref: :471-506."""
+        if self.savedForBackward is None:                                             # ref: :478-479
+            raise ValueError('Need savedIndices to be able to call backward()')
+        _lib.require_device_f32(grad_output, 'grad_output')
+        idx = self.savedForBackward.raw_indices()
+        k = self.savedForBackward['numPoints']
+        alpha = self.savedForBackward['scalingFactor']
+        g = grad_output.contiguous()
+        n = g.numel()
+        if idx.numel() != n:
+            raise ValueError('grad_output must have as many elements as the quantized tensor')
+        grad_points = torch.empty(k, dtype=torch.float32, device=g.device)
+        ws = _lib.workspace(g.device)
+        _lib.check(_lib.load().qd_point_grad_f32(
+            g.data_ptr(), idx.data_ptr(), 8 if idx.dtype == torch.int64 else 1, alpha.data_ptr(), n,
+            _bucket_arg(self.bucket_size), int(k), grad_points.data_ptr(), ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr()))
+        self.savedIndices = None                                                      # ref: :505
+        return grad_output, grad_points

@@ -1,0 +1,379 @@
+"""GPU parity tests: the HIP path (through the `quantization` API and the C ABI) against the
+golden vectors produced by the reference and against the CPU oracle.
+
+Bar: bit-exact for q, alpha, beta, arg indices, level indices and point indices; tolerance only
+where an fp32 summation order is involved (mean, point gradient, 'complicated' STE sum)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import quantization
+import quantization.help_functions as qhf
+from oracle import oracle_c as oc
+from oracle import oracle_np as onp
+from quantized_distillation_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    _lib.load()
+    oc.build()
+
+
+# ------------------------------------------------------------------------------ uniform (K1/K1g/K2/K3)
+def test_uniform_golden(golden_uniform):
+    G = golden_uniform
+    for i, c in enumerate(G.meta):
+        x = G.arr('u', i, 'x')
+        tag = 'case %d %r' % (i, c)
+        xd = dev(x)
+        q, sf = quantization.uniformQuantization(xd, c['s'], bucket_size=c['bucket'], max_element=c['max_element'],
+                                                 subtract_mean=c['subtract_mean'])
+        assert torch.equal(xd.cpu(), torch.from_numpy(x)), 'input modified: ' + tag
+        assert q.shape == xd.shape and q.dtype == torch.float32 and q.device == xd.device
+        assert list(sf.expected_tensor_size) == c['expected_tensor_size'], tag
+        assert sf.original_tensor_length == c['original_tensor_length'] and tuple(sf.original_tensor_size) == x.shape
+        assert tuple(sf.alpha.shape) == G.arr('u', i, 'alpha').shape, tag
+        if c['subtract_mean']:
+            m = float(sf.mean_tensor)
+            assert abs(m - c['mean']) <= 2e-7 * max(1.0, abs(c['mean'])) + 1e-9, tag
+            # everything downstream of the mean is bit-exact given the mean the device computed
+            ref = onp.uniform_quantize(x, c['s'], c['bucket'], c['max_element'], True, mean=m)
+            assert np.array_equal(host(q), ref['q']), tag
+            assert np.array_equal(host(sf.alpha).reshape(-1), ref['alpha'].reshape(-1)), tag
+            continue
+        assert np.array_equal(host(q), G.arr('u', i, 'q')), tag
+        assert np.array_equal(host(sf.alpha), G.arr('u', i, 'alpha')), tag
+        assert np.array_equal(host(sf.beta), G.arr('u', i, 'beta')), tag
+        assert np.array_equal(host(sf.idx_min_rows), G.arr('u', i, 'imin')), tag
+        assert np.array_equal(host(sf.idx_max_rows), G.arr('u', i, 'imax')), tag
+        assert sf.idx_min_rows.dtype == torch.int64
+
+
+def test_scale_down_and_inverse_golden(golden_uniform):
+    G = golden_uniform
+    for i, c in enumerate(G.meta):
+        if c['subtract_mean']:
+            continue
+        x = G.arr('u', i, 'x')
+        sf = quantization.ScalingFunction('linear', c['max_element'], False, c['bucket'])
+        u = sf.scale_down(dev(x))
+        tag = 'case %d %r' % (i, c)
+        assert np.array_equal(host(u), G.arr('u', i, 'u')), tag            # padded bucket layout, bit-exact
+        assert np.array_equal(host(sf.alpha), G.arr('u', i, 'alpha')), tag
+        assert np.array_equal(host(sf.idx_max_rows), G.arr('u', i, 'imax')), tag
+        back = sf.inv_scale_down(u)
+        ref = onp.inv_scale_down(G.arr('u', i, 'u'), G.arr('u', i, 'alpha'), G.arr('u', i, 'beta'), 0.0, x.size, x.shape)
+        assert np.array_equal(host(back), ref), tag
+        with pytest.raises(ValueError):
+            sf.inv_scale_down(torch.zeros(u.numel() + 1, device=DEV))
+
+
+def test_roundtrip_golden(golden_misc):
+    G = golden_misc
+    for i, c in enumerate(G.meta['roundtrip']):
+        sf = quantization.ScalingFunction('linear', False, False, c['bucket'])
+        u = sf.scale_down(dev(G.z['rt%d_x' % i]))
+        assert np.array_equal(host(u), G.z['rt%d_u' % i])
+        assert np.array_equal(host(sf.inv_scale_down(u)), G.z['rt%d_back' % i])
+
+
+def test_level_index_output_via_c_abi(golden_uniform):
+    """The integer path: uint8 level index rint(u*(s-1)) straight from the C ABI, bit-exact."""
+    G = golden_uniform
+    lib = _lib.load()
+    for i, c in enumerate(G.meta):
+        if c['subtract_mean'] or c['max_element'] is not False or c['s'] > 256:
+            continue
+        x = G.arr('u', i, 'x')
+        n = x.size
+        xd = dev(x).view(-1)
+        q = torch.empty_like(xd)
+        lev = torch.full((n + 3,), 255, dtype=torch.uint8, device=DEV)[:n]
+        ws = _lib.workspace(xd.device)
+        _lib.check(lib.qd_uniform_f32(xd.data_ptr(), q.data_ptr(), n, c['bucket'] or 0, c['s'], None, None,
+                                      lev.data_ptr(), None, 0, 0.0, 0, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        want = G.arr('u', i, 'lev').reshape(-1)[:n]
+        assert np.array_equal(host(lev).astype(np.int32), want), (i, c)
+        assert np.array_equal(host(q), G.arr('u', i, 'q').reshape(-1)), (i, c)
+
+
+def test_modify_in_place_and_views():
+    x = torch.randn(5000, generator=torch.Generator().manual_seed(3))
+    ref = onp.uniform_quantize(x.numpy(), 16, 256)['q']
+    xd = x.to(DEV)
+    q, sf = quantization.uniformQuantization(xd, 16, bucket_size=256, modify_in_place=True)
+    assert q.data_ptr() == xd.data_ptr() and np.array_equal(host(xd), ref)
+    # arg indices were taken before the overwrite
+    assert np.array_equal(host(sf.idx_min_rows).reshape(-1), onp.scale_down(x.numpy(), 256)['imin'].reshape(-1))
+    # misaligned view (4-byte aligned base): generic path
+    big = torch.zeros(5001, device=DEV)
+    big[1:] = x.to(DEV)
+    q, _ = quantization.uniformQuantization(big[1:], 16, bucket_size=256)
+    assert np.array_equal(host(q), ref)
+    q, _ = quantization.uniformQuantization(big[1:], 16)
+    assert np.array_equal(host(q), onp.uniform_quantize(x.numpy(), 16, None)['q'])
+    # non-contiguous input is accepted (made contiguous)
+    m = torch.randn(64, 48, generator=torch.Generator().manual_seed(4))
+    q, _ = quantization.uniformQuantization(m.to(DEV).t(), 4, bucket_size=256)
+    assert np.array_equal(host(q), onp.uniform_quantize(m.t().contiguous().numpy(), 4, 256)['q'])
+    # empty tensor
+    q, sf = quantization.uniformQuantization(torch.empty(0, device=DEV), 16, bucket_size=256)
+    assert q.numel() == 0
+
+
+@pytest.mark.parametrize('bucket', [64, 128, 256, 512, 1024, 2048, 4096, 100, 3, None])
+def test_uniform_random_sweep_vs_c_oracle(bucket):
+    rng = np.random.RandomState(11)
+    for n in (1, 63, 64, 1000, 4097, 70001, 262144 + 5):
+        for s in (2, 16, 256):
+            x = (rng.randn(n) * rng.choice([0.05, 1.0, 30.0])).astype(np.float32)
+            q, sf = quantization.uniformQuantization(dev(x), s, bucket_size=bucket)
+            r = oc.uniform_quantize(x, s, bucket)
+            assert np.array_equal(host(q), r['q']), (n, s, bucket)
+            assert np.array_equal(host(sf.alpha).reshape(-1), r['alpha']), (n, s, bucket)
+            assert np.array_equal(host(sf.beta).reshape(-1), r['beta']), (n, s, bucket)
+            assert np.array_equal(host(sf.idx_min_rows).reshape(-1), r['imin']), (n, s, bucket)
+            assert np.array_equal(host(sf.idx_max_rows).reshape(-1), r['imax']), (n, s, bucket)
+
+
+def test_uniform_big_checksums_from_reference(golden_big):
+    for c in golden_big:
+        if c['op'] != 'uniform':
+            continue
+        x = torch.randn(c['n'], generator=torch.Generator().manual_seed(c['seed']))
+        q, _ = quantization.uniformQuantization(x.to(DEV), c['s'], bucket_size=c['bucket'])
+        qh = host(q)
+        s1, s2 = oc.checksum(qh)
+        assert abs(s1 - c['sum_q']) <= 1e-9 * c['sum_q2'] and abs(s2 - c['sum_q2']) <= 1e-9 * c['sum_q2'], c
+        assert [float(v) for v in qh[:5]] == c['q_head'] and [float(v) for v in qh[-3:]] == c['q_tail']
+
+
+def test_headline_size_properties_and_oracle():
+    """BASELINE.json's workload: 64 Mi fp32, 4-bit, bucket 256.  Full bit-exact comparison with
+    the C oracle plus size-independent properties (idempotence, level membership)."""
+    n = 64 * 1024 * 1024
+    x = torch.randn(n, generator=torch.Generator().manual_seed(0))
+    xd = x.to(DEV)
+    q, sf = quantization.uniformQuantization(xd, 16, bucket_size=256)
+    q2, _ = quantization.uniformQuantization(q, 16, bucket_size=256)
+    assert torch.equal(q, q2), 'Q(Q(x)) != Q(x)'
+    # every output is one of the 16 levels of its bucket: (q - beta)/alpha*15 is an integer
+    lev = torch.round((q.view(-1, 256) - sf.beta) / sf.alpha * 15)
+    assert float(lev.min()) == 0.0 and float(lev.max()) == 15.0
+    assert torch.equal(q.view(-1, 256).min(dim=1, keepdim=True)[0], sf.beta)
+    r = oc.uniform_quantize(x.numpy(), 16, 256, want_idx=False, want_lev=False)
+    assert np.array_equal(host(q), r['q'])
+    assert np.array_equal(host(sf.alpha).reshape(-1), r['alpha'])
+    # same tensor without buckets, and a ragged length
+    qg, _ = quantization.uniformQuantization(xd, 16)
+    assert np.array_equal(host(qg), oc.uniform_quantize(x.numpy(), 16, None, want_idx=False, want_lev=False)['q'])
+    xr = xd[:n - 239]
+    qr, _ = quantization.uniformQuantization(xr, 4, bucket_size=256)
+    assert np.array_equal(host(qr), oc.uniform_quantize(x.numpy()[:n - 239], 4, 256, want_idx=False, want_lev=False)['q'])
+
+
+def test_stochastic_rounding_statistics():
+    """In-kernel counter-based RNG cannot be bit-matched to torch's host RNG (the reference draws
+    torch.rand on the host, quant_functions.py:185-186): check the statistics instead."""
+    torch.manual_seed(5)
+    n = 1 << 20
+    x = torch.rand(n, generator=torch.Generator().manual_seed(6))
+    x[0], x[1] = 0.0, 1.0
+    xd = x.to(DEV)
+    s = 4
+    q, _ = quantization.uniformQuantization(xd, s, stochastic_rounding=True)
+    qh, xh = host(q).astype(np.float64), x.numpy().astype(np.float64)
+    t = xh * (s - 1)
+    lo, hi = np.floor(t) / (s - 1), np.ceil(t) / (s - 1)
+    assert np.all((np.abs(qh - lo) < 1e-6) | (np.abs(qh - hi) < 1e-6)), 'not one of the two neighbouring levels'
+    assert abs((qh - xh).mean()) < 3e-4, 'stochastic rounding must be unbiased'
+    up = np.abs(qh - hi) < 1e-6
+    frac = t - np.floor(t)
+    sel = (frac > 0.2) & (frac < 0.3)
+    assert abs(up[sel].mean() - frac[sel].mean()) < 0.01
+    q2, _ = quantization.uniformQuantization(xd, s, stochastic_rounding=True)
+    assert not torch.equal(q, q2), 'successive calls must use different random streams'
+    qb, _ = quantization.uniformQuantization(xd, s, stochastic_rounding=True, bucket_size=256)
+    assert abs((host(qb).astype(np.float64) - xh).mean()) < 3e-4
+
+
+# ------------------------------------------------------------------------------ non-uniform (K4/K5/K6)
+def test_nonuniform_golden(golden_nonuniform):
+    G = golden_nonuniform
+    for i, c in enumerate(G.meta):
+        x, pts = G.arr('n', i, 'x'), G.arr('n', i, 'pts')
+        tag = 'case %d %r' % (i, c)
+        xd = dev(x)
+        q, idx, sf = quantization.nonUniformQuantization(xd, dev(pts), bucket_size=c['bucket'])
+        assert idx.dtype == torch.int64 and idx.shape == xd.shape
+        assert np.array_equal(host(idx), G.arr('n', i, 'idx')), tag
+        assert np.array_equal(host(q), G.arr('n', i, 'q')), tag
+        assert np.array_equal(host(sf.alpha), G.arr('n', i, 'alpha')), tag
+        # list of python floats and CPU tensor of points are accepted too
+        q_l, idx_l, _ = quantization.nonUniformQuantization(xd, [float(v) for v in pts], bucket_size=c['bucket'])
+        assert torch.equal(q_l, q) and torch.equal(idx_l, idx)
+        # pre-processed variable: midpoint rule, first and second query, gradients
+        fn = quantization.nonUniformQuantization_variable(bucket_size=c['bucket'], pre_process_tensors=True, tensor=xd)
+        qp = fn.forward(None, dev(pts))
+        assert np.array_equal(host(qp), G.arr('n', i, 'q_pre')), tag
+        assert np.array_equal(host(fn.savedForBackward['indices']), G.arr('n', i, 'idx_pre')), tag
+        assert fn.savedForBackward['indices'].dtype == torch.int64 and fn.savedForBackward['numPoints'] == c['k']
+        g = G.arr('n', i, 'g')
+        gin, gp = fn.backward(dev(g))
+        assert gin.data_ptr() == gin.data_ptr() and np.array_equal(host(gin), g)
+        want, absum = onp.point_grad(g, G.arr('n', i, 'idx_pre'), G.arr('n', i, 'alpha'), c['bucket'], c['k'])
+        assert np.all(np.abs(host(gp).astype(np.float64) - want) <= 2e-6 * absum + 1e-30), tag
+        assert np.all(np.abs(host(gp).astype(np.float64) - G.arr('n', i, 'gp')) <= 4e-6 * absum + 1e-30), tag
+        qp2 = fn.forward(None, dev(G.arr('n', i, 'pts2')))
+        assert np.array_equal(host(qp2), G.arr('n', i, 'q_pre2')), tag
+        assert np.array_equal(host(fn.savedForBackward['indices']), G.arr('n', i, 'idx_pre2')), tag
+        # non-preprocessed variable = the plain function
+        fn2 = quantization.nonUniformQuantization_variable(bucket_size=c['bucket'])
+        assert torch.equal(fn2.forward(xd, dev(pts)), q)
+        _, gp2 = fn2.backward(dev(g))
+        want2, absum2 = onp.point_grad(g, G.arr('n', i, 'idx'), G.arr('n', i, 'alpha'), c['bucket'], c['k'])
+        assert np.all(np.abs(host(gp2).astype(np.float64) - want2) <= 2e-6 * absum2 + 1e-30), tag
+
+
+@pytest.mark.parametrize('k', [2, 4, 16, 33, 256, 1000])
+def test_nonuniform_random_vs_c_oracle(k):
+    rng = np.random.RandomState(k)
+    for n, bucket in [(100003, 256), (100003, None), (5000, 100), (1 << 20, 256), (300, 256)]:
+        x = rng.randn(n).astype(np.float32)
+        pts = np.sort(rng.rand(k)).astype(np.float32)
+        for mode in ('distance', 'midpoint'):
+            r = oc.nonuniform_quantize(x, pts, bucket, mode)
+            if mode == 'distance':
+                q, idx, sf = quantization.nonUniformQuantization(dev(x), dev(pts), bucket_size=bucket)
+            else:
+                fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=dev(x))
+                q = fn.forward(None, dev(pts))
+                idx = fn.savedForBackward['indices']
+                g = rng.randn(n).astype(np.float32)
+                _, gp = fn.backward(dev(g))
+                want, absum = oc.point_grad(g, r['idx'], r['alpha'], bucket, k)
+                assert np.all(np.abs(host(gp).astype(np.float64) - want) <= 4e-6 * absum + 1e-30), (n, bucket, k)
+                # determinism: same inputs, same bits
+                _, gp_again = fn.backward(dev(g))
+                assert torch.equal(gp, gp_again) or k > 16
+            assert np.array_equal(host(idx), r['idx']), (n, bucket, mode)
+            assert np.array_equal(host(q), r['q']), (n, bucket, mode)
+            assert np.bincount(host(idx).reshape(-1), minlength=k).sum() == n
+
+
+def test_search_sorted_handle_query():
+    from quantization.quant_functions import SearchSorted
+    x = np.random.RandomState(0).rand(10000).astype(np.float32)
+    pts = np.array([0.0, 0.3, 0.31, 0.9], dtype=np.float32)
+    idx = SearchSorted(dev(x)).query(dev(pts))
+    assert np.array_equal(host(idx), onp.assign_midpoint(x, pts))
+
+
+def test_init_points_and_huffman_golden(golden_misc):
+    G = golden_misc
+    for i, c in enumerate(G.meta['init_points']):
+        sf = quantization.ScalingFunction('linear', False, False, c['bucket'], False)
+        p = qhf.initialize_quantization_points(dev(G.z['ip%d_x' % i]), sf, c['k'])
+        assert p.is_cuda and np.array_equal(host(p), G.z['ip%d_p' % i]), c
+    params = [dev(G.z['hf_p%d' % j]) for j in range(4)]
+    for c in G.meta['huffman']:
+        if c['kind'] == 'uniform':
+            f = lambda t, c=c: quantization.uniformQuantization(t, c['s'], bucket_size=c['bucket'])   # noqa: E731
+            got = qhf.get_huffman_encoding_mean_bit_length(iter(params), f, 'uniform', s=c['s'])
+        else:
+            pts = torch.tensor(c['points'])
+            f = lambda t, pts=pts, c=c: quantization.nonUniformQuantization(t, pts, bucket_size=c['bucket'])   # noqa: E731
+            got = qhf.get_huffman_encoding_mean_bit_length(iter(params), f, 'nonuniform')
+        assert abs(got - c['mean_bit_length']) < 1e-12, (c, got)
+
+
+# ------------------------------------------------------------------------------ STE variants (K7/K8)
+def test_ste_complicated_golden(golden_ste):
+    G = golden_ste
+    for i, c in enumerate(G.meta):
+        x, g = G.arr('s', i, 'x'), G.arr('s', i, 'g')
+        fn = quantization.uniformQuantization_variable(c['s'], bucket_size=c['bucket'])
+        q = fn.forward(dev(x))
+        assert np.array_equal(host(q), G.arr('s', i, 'q'))
+        out = fn.backward(dev(g))
+        assert fn.saved_for_backward is None
+        scale = np.abs(g).sum() / g.size * c['bucket']
+        assert np.allclose(host(out), G.arr('s', i, 'gout'), rtol=0, atol=3e-6 * scale), (i, c)
+        ref = onp.ste_complicated_backward(x, g, c['s'], c['bucket'])
+        assert np.allclose(host(out), ref, rtol=0, atol=3e-6 * scale), (i, c)
+        # exactly the same positions are touched as in the oracle (the tie rule, integer path)
+        assert np.array_equal(host(out) != g, ref != g), (i, c)
+
+
+def test_ste_complicated_large_vs_c_oracle():
+    rng = np.random.RandomState(2)
+    for n, bucket, s in [(1 << 20, 256, 16), (100003, 256, 4), (50000, 100, 16)]:
+        x = rng.randn(n).astype(np.float32)
+        g = rng.randn(n).astype(np.float32)
+        fn = quantization.uniformQuantization_variable(s, bucket_size=bucket)
+        fn.forward(dev(x))
+        out = host(fn.backward(dev(g)))
+        ref = oc.ste_complicated_backward(x, g, s, bucket)
+        assert np.array_equal(out != g, ref != g)
+        assert np.allclose(out, ref, rtol=0, atol=3e-6 * np.abs(g).mean() * bucket)
+
+
+def test_truncated_ste_kernels():
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    w = (rng.randn(100001) * 0.8).astype(np.float32)
+    g = rng.randn(100001).astype(np.float32)
+    wd, gd = dev(w), dev(g)
+    _lib.check(lib.qd_truncated_ste_f32(wd.data_ptr(), gd.data_ptr(), w.size, 1.0, _lib.stream_ptr()))
+    assert np.array_equal(host(gd), onp.truncated_ste_mask(w, g))
+    _lib.check(lib.qd_clamp_f32(wd.data_ptr(), w.size, 1.0, _lib.stream_ptr()))
+    assert np.array_equal(host(wd), np.clip(w, -1.0, 1.0))
+
+
+# ------------------------------------------------------------------------------ multi-tensor K1
+def test_multi_tensor_matches_per_tensor():
+    from quantized_distillation_amd.multi_tensor import MultiTensorQuantizer
+    g = torch.Generator().manual_seed(9)
+    shapes = [(500, 1600), (50, 75, 5, 5), (50,), (10,), (1,), (257,), (256,), (50, 50, 5, 5), (3, 3), (1025,)]
+    for bucket in (256, 128, 100):
+        masters = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
+        mt = MultiTensorQuantizer(masters, 16, bucket)
+        outs = mt.quantize()
+        for m, o in zip(masters, outs):
+            want, _ = quantization.uniformQuantization(m, 16, bucket_size=bucket)
+            assert torch.equal(o, want), (bucket, tuple(m.shape))
+            assert np.array_equal(host(o), onp.uniform_quantize(host(m), 16, bucket)['q'])
+        # masters untouched; a second call after an update sees the new values
+        masters[0].mul_(0.5)
+        outs = mt.quantize()
+        assert torch.equal(outs[0], quantization.uniformQuantization(masters[0], 16, bucket_size=bucket)[0])
+
+
+def test_c_abi_argument_errors():
+    lib = _lib.load()
+    x = torch.zeros(16, device=DEV)
+    assert lib.qd_uniform_f32(x.data_ptr(), x.data_ptr(), 16, 4, 1, None, None, None, None, 0, 0.0, 0, 0, None, 0,
+                              _lib.stream_ptr()) == -1          # levels < 2
+    assert lib.qd_uniform_f32(None, x.data_ptr(), 16, 4, 16, None, None, None, None, 0, 0.0, 0, 0, None, 0,
+                              _lib.stream_ptr()) == -1          # null input
+    big = torch.zeros(100000, device=DEV)
+    assert lib.qd_uniform_f32(big.data_ptr(), big.data_ptr(), 100000, 0, 16, None, None, None, None, 0, 0.0, 0, 0,
+                              None, 0, _lib.stream_ptr()) == -2  # global path needs the workspace
+    with pytest.raises(RuntimeError):
+        _lib.check(-2)

@@ -1,0 +1,109 @@
+"""Host-side behaviour of the `quantization` mirror that needs no GPU: argument validation and
+exceptions (same as the reference), pure-host helpers against golden values, and the loud
+failure on CPU tensors (this package has no CPU path)."""
+import numpy as np
+import pytest
+import torch
+
+import quantization
+import quantization.help_functions as qhf
+from quantized_distillation_amd import _lib
+
+
+def test_public_names():
+    for name in ('uniformQuantization', 'ScalingFunction', 'nonUniformQuantization',
+                 'uniformQuantization_variable', 'nonUniformQuantization_variable'):
+        assert hasattr(quantization, name)
+    assert isinstance(quantization.USE_CUDA, bool)
+    import quantization.quant_functions as qf
+    assert hasattr(qf, 'SearchSorted')
+
+
+def test_scaling_function_validation():
+    SF = quantization.ScalingFunction
+    SF('Linear', False, False, None)                      # case-insensitive
+    with pytest.raises(ValueError):
+        SF('foo', False, False, None)
+    for bad in (0, -4, 2.5, np.int64(256)):
+        with pytest.raises(ValueError):
+            SF('linear', False, False, bad)
+    with pytest.raises(ValueError):
+        SF('linear', True, False, None)                   # a bool is refused; pass a number or False
+    sf = SF('linear', 0.5, True, 256, False)
+    assert sf.tol_diff_zero == 1e-10 and sf.alpha is None and sf.bucket_size == 256
+
+
+def test_cpu_tensors_fail_loudly():
+    x = torch.randn(100)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        quantization.uniformQuantization(x, 16, bucket_size=256)
+    with pytest.raises(RuntimeError, match='HIP device'):
+        quantization.nonUniformQuantization(x, [0.0, 1.0])
+    with pytest.raises(RuntimeError, match='HIP device'):
+        quantization.ScalingFunction('linear', False, False, None).scale_down(x)
+
+
+def test_nonuniform_argument_errors():
+    x = torch.randn(10)
+    with pytest.raises(ValueError):
+        quantization.nonUniformQuantization(x, [0.0, 1.0], pre_processed_values=True)
+    with pytest.raises(ValueError):
+        quantization.nonUniformQuantization(x, [0.0, 1.0], scaling_function=object())
+    with pytest.raises(ValueError):
+        quantization.nonUniformQuantization_variable(pre_process_tensors=True)
+    fn = quantization.nonUniformQuantization_variable()
+    with pytest.raises(ValueError):
+        fn.forward(x, torch.zeros(2, 2))
+    with pytest.raises(ValueError):
+        fn.backward(x)
+
+
+def test_uniform_variable_backward_guards():
+    g = torch.randn(4)
+    with pytest.raises(ValueError):
+        quantization.uniformQuantization_variable(16, type_of_scaling='absmax', bucket_size=4).backward(g)
+    with pytest.raises(NotImplementedError):
+        quantization.uniformQuantization_variable(16, subtract_mean=True, bucket_size=4).backward(g)
+    with pytest.raises(NotImplementedError):
+        quantization.uniformQuantization_variable(16).backward(g)
+    with pytest.raises(ValueError):
+        quantization.uniformQuantization_variable(16, bucket_size=4).backward(g)
+
+
+def test_assign_bits_matches_reference(golden_misc):
+    for c in golden_misc.meta['assign_bits']:
+        got = qhf.assign_bits_automatically(c['norms'], c['init'], input_is_point=c['input_is_point'])
+        assert got == c['result']
+        assert sum(got) == (c['init'] * len(c['norms']) if isinstance(c['init'], int) else sum(c['init']))
+    with pytest.raises(ValueError):
+        qhf.assign_bits_automatically([1.0, 2.0], [4])
+
+
+def test_huffman_encode():
+    code = dict(qhf.huffman_encode({'a': 0.5, 'b': 0.25, 'c': 0.125, 'd': 0.125}))
+    assert sorted(len(v) for v in code.values()) == [1, 2, 3, 3]
+    assert len(code['a']) == 1
+    # prefix free
+    vals = list(code.values())
+    assert not any(a != b and b.startswith(a) for a in vals for b in vals)
+    with pytest.raises(ValueError):
+        qhf.get_huffman_encoding_mean_bit_length([], None, 'weird')
+    with pytest.raises(ValueError):
+        qhf.get_huffman_encoding_mean_bit_length([], None, 'uniform')
+
+
+def test_create_bucket_tensor_layout():
+    x = torch.arange(10, dtype=torch.float32)
+    b = qhf.create_bucket_tensor(x, 4)
+    assert b.shape == (3, 4) and b[2].tolist() == [8, 9, 9, 9]
+    assert qhf.create_bucket_tensor(x, 16).shape == (1, 10)
+    assert qhf.create_bucket_tensor(x, None) is x
+    assert qhf.create_bucket_tensor(x[:8], 4).shape == (2, 4)
+    assert torch.isnan(qhf.create_bucket_tensor(x, 4, fill_values='nan')[2, 2:]).all()
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.QdLibraryMissing):
+        _lib.load()

@@ -129,3 +129,16 @@ def test_bucket_geometry():
     assert onp.bucket_geometry(1024, 256) == (4, 256, 1024)
     assert onp.bucket_geometry(3, 256) == (1, 3, 3)
     assert onp.bucket_geometry(77, None) == (1, 77, 77)
+
+
+def test_torch_port(golden_uniform):
+    """oracle/torch_port.py (the op-for-op torch CPU port timed by bench.py) against the golden set."""
+    import torch
+    from oracle.torch_port import uniform_quantize_torch_ops
+    G = golden_uniform
+    for i, c in enumerate(G.meta):
+        if c['subtract_mean'] or c['max_element'] is not False:
+            continue
+        q, alpha, beta = uniform_quantize_torch_ops(torch.from_numpy(G.arr('u', i, 'x')), c['s'], c['bucket'])
+        assert np.array_equal(q.numpy(), G.arr('u', i, 'q')), (i, c)
+        assert np.array_equal(alpha.numpy().reshape(-1), G.arr('u', i, 'alpha').reshape(-1)), (i, c)
