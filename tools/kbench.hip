@@ -1,0 +1,175 @@
+// kbench.hip -- standalone A/B harness for the headline kernel (not part of the product).
+// Variants of the 256-element-bucket quantize-dequantize next to pure copies of the same bytes,
+// interleaved rounds, hipEvent timing, 4 rotating buffer pairs (512 MiB per call > 256 MiB MALL).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I quantized_distillation_amd/csrc tools/kbench.hip -o build/kbench
+#include "qd_common.h"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <string>
+#include <functional>
+using namespace qd;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <bool NT> __device__ __forceinline__ f4 ld(const f4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void st(f4 v, f4* p) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// copy with the same access geometry as the quant kernel: a wave moves 4 KiB per iteration
+template <bool NT, int V>
+__global__ __launch_bounds__(256) void k_copy(const f4* x, f4* y, int64_t n4) {
+    const int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    const int64_t wave = base >> 6; const int lane = threadIdx.x & 63;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ntiles = n4 / (64 * V);
+    for (int64_t t = wave; t < ntiles; t += nw) {
+        f4 v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = ld<NT>(x + t * 64 * V + j * 64 + lane);
+#pragma unroll
+        for (int j = 0; j < V; ++j) st<NT>(v[j], y + t * 64 * V + j * 64 + lane);
+    }
+}
+
+// DIVMODE 0: IEEE division (product); 1: multiply by reciprocal (NOT bit exact, VALU-cost probe)
+template <bool NT, int LPB, int V, int DIVMODE>
+__global__ void k_qdq(const float* x, float* q, int64_t nb, float sm1) {
+    constexpr int BPW = 64 / LPB;
+    constexpr int ROW = LPB * V * 4;
+    const int lane = threadIdx.x & 63, sub = lane / LPB, l = lane % LPB;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ntiles = (nb + BPW - 1) / BPW;
+    for (int64_t t = wave; t < ntiles; t += nw) {
+        const int64_t bkt = t * BPW + sub;
+        if (bkt >= nb) continue;
+        const int64_t e0 = bkt * ROW + l * 4;
+        const f4* src = (const f4*)(x + e0);
+        f4 v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = ld<NT>(src + j * LPB);
+        float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
+        float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+#pragma unroll
+        for (int j = 1; j < V; ++j) {
+            mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
+            mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+        }
+        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); } else { mn = wave_min(mn); mx = wave_max(mx); }
+        float a, b; alpha_beta(mn, mx, a, b);
+        const float ra = 1.0f / a, rs = 1.0f / sm1;
+        f4* dst = (f4*)(q + e0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            f4 r; float lev;
+            if (DIVMODE == 0) {
+                r.x = qdq(v[j].x, a, b, sm1, 0.f, lev); r.y = qdq(v[j].y, a, b, sm1, 0.f, lev);
+                r.z = qdq(v[j].z, a, b, sm1, 0.f, lev); r.w = qdq(v[j].w, a, b, sm1, 0.f, lev);
+            } else {
+#define QF(c) { float u = (v[j].c - b) * ra; float w = rintf(u * sm1) * rs; r.c = w * a + b; }
+                QF(x) QF(y) QF(z) QF(w)
+#undef QF
+            }
+            st<NT>(r, dst + j * LPB);
+        }
+    }
+}
+
+struct Variant { std::string name; std::function<void(int)> run; std::vector<float> us; };
+
+int main(int argc, char** argv) {
+    const int64_t N = 64ll << 20;
+    const int64_t nb = N / 256;
+    float *x[4], *y[4];
+    std::vector<float> h(N);
+    uint32_t s = 12345;
+    // data=lcg : 24-bit integers scaled to [-2,2) (low-entropy low mantissa bits)
+    // data=bits: random sign, exponent in [2^-4, 2^3), 23 fully random mantissa bits (what randn weights look like)
+    // data=zero: all zeros
+    const std::string data = argc > 2 ? argv[2] : "lcg";
+    uint64_t z = 88172645463325252ull;
+    for (int64_t i = 0; i < N; ++i) {
+        if (data == "bits") {
+            z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+            uint32_t r = (uint32_t)(z >> 20);
+            uint32_t bits = (r & 0x807FFFFFu) | ((123u + ((r >> 23) & 7u)) << 23);
+            memcpy(&h[i], &bits, 4);
+        } else if (data == "zero") {
+            h[i] = 0.0f;
+        } else {
+            s = s * 1664525u + 1013904223u; h[i] = ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 22));
+        }
+    }
+    printf("data=%s\n", data.c_str());
+    for (int i = 0; i < 4; ++i) {
+        CK(hipMalloc(&x[i], N * 4)); CK(hipMalloc(&y[i], N * 4));
+        CK(hipMemcpy(x[i], h.data(), N * 4, hipMemcpyHostToDevice));
+    }
+    hipStream_t st0; CK(hipStreamCreate(&st0));
+    std::vector<Variant> vs;
+    auto addq = [&](const char* nm, auto kern, int block, int64_t tiles_per_wave_iter, int64_t cap) {
+        vs.push_back({nm, [=](int i) {
+            int64_t waves = tiles_per_wave_iter; int64_t blocks = (waves * 64 + block - 1) / block; if (cap > 0 && blocks > cap) blocks = cap;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(block), 0, st0, (const float*)x[i & 3], y[i & 3], nb, 15.0f);
+        }, {}});
+    };
+    auto addc = [&](const char* nm, auto kern, int V, int64_t cap) {
+        vs.push_back({nm, [=](int i) {
+            int64_t waves = N / 4 / (64 * V); int64_t blocks = waves / 4; if (cap > 0 && blocks > cap) blocks = cap;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st0, (const f4*)x[i & 3], (f4*)y[i & 3], N / 4);
+        }, {}});
+    };
+    addc("copy nt V4 full", k_copy<true, 4>, 4, 0);
+    addc("copy plain V4 full", k_copy<false, 4>, 4, 0);
+    addc("copy nt V1 full", k_copy<true, 1>, 1, 0);
+    addc("copy nt V4 cap2048", k_copy<true, 4>, 4, 2048);
+    addc("copy nt V8 full", k_copy<true, 8>, 8, 0);
+    addq("qdq nt L16V4 b256 full", k_qdq<true, 16, 4, 0>, 256, nb / 4, 0);
+    addq("qdq plain L16V4 b256 full", k_qdq<false, 16, 4, 0>, 256, nb / 4, 0);
+    addq("qdq nt L16V4 b64 full", k_qdq<true, 16, 4, 0>, 64, nb / 4, 0);
+    addq("qdq nt L16V4 b128 full", k_qdq<true, 16, 4, 0>, 128, nb / 4, 0);
+    addq("qdq nt L16V4 b512 full", k_qdq<true, 16, 4, 0>, 512, nb / 4, 0);
+    addq("qdq nt L16V4 b1024 full", k_qdq<true, 16, 4, 0>, 1024, nb / 4, 0);
+    addq("qdq nt L64V1 b256 full", k_qdq<true, 64, 1, 0>, 256, nb, 0);
+    addq("qdq nt L16V4 b256 cap8192", k_qdq<true, 16, 4, 0>, 256, nb / 4, 8192);
+    addq("qdq nt L16V4 b256 cap2048", k_qdq<true, 16, 4, 0>, 256, nb / 4, 2048);
+    addq("qdq nt L16V4 b256 rcp(not exact)", k_qdq<true, 16, 4, 1>, 256, nb / 4, 0);
+    // sustained mode: the chip's power management cuts clocks after a few ms of continuous
+    // streaming; report 100-launch chunks of an uninterrupted 800-launch run per variant
+    if (argc > 1 && std::string(argv[1]) == "sustained") {
+        std::vector<hipEvent_t> ev(9);
+        for (auto& evt : ev) CK(hipEventCreate(&evt));
+        for (auto& v : vs) {
+            CK(hipStreamSynchronize(st0));
+            CK(hipEventRecord(ev[0], st0));
+            for (int c = 0; c < 8; ++c) {
+                for (int i = 0; i < 100; ++i) v.run(i);
+                CK(hipEventRecord(ev[c + 1], st0));
+            }
+            CK(hipEventSynchronize(ev[8]));
+            printf("%-36s", v.name.c_str());
+            for (int c = 0; c < 8; ++c) { float ms; CK(hipEventElapsedTime(&ms, ev[c], ev[c + 1])); printf(" %7.2f", ms * 10.f); }
+            printf("  us/launch per 100-launch chunk\n");
+        }
+        return 0;
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 20, rounds = 5;
+    for (int r = 0; r < rounds; ++r)
+        for (auto& v : vs) {
+            for (int i = 0; i < 3; ++i) v.run(i);
+            CK(hipEventRecord(e0, st0));
+            for (int i = 0; i < iters; ++i) v.run(i);
+            CK(hipEventRecord(e1, st0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            v.us.push_back(ms * 1e3f / iters);
+        }
+    printf("%-36s %10s %10s %12s\n", "variant", "min us", "med us", "GB/s@min");
+    for (auto& v : vs) {
+        std::sort(v.us.begin(), v.us.end());
+        printf("%-36s %10.2f %10.2f %12.1f\n", v.name.c_str(), v.us[0], v.us[v.us.size() / 2], 8.0 * N / v.us[0] / 1e3);
+    }
+    return 0;
+}
