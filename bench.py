@@ -94,6 +94,71 @@ def cpu_baseline(x_host):
     return out
 
 
+def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, per_gpu_batch=50):
+    """Second half of BASELINE.json's metric: distilled-training steps/sec on synthetic
+    CIFAR10-shaped data (configs[1]: ConvolForwardNet student, 4-bit uniform quantization, bucket
+    256, pure STE), data parallel over the ranks with one RCCL all-reduce of the flat gradient
+    per step.  Weak scaling: per-GPU batch fixed at 50."""
+    import torch.distributed as dist
+    from harness import models
+    from harness.distill import DistillTrainer, synthetic_batch
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    out = {'config': 'CIFAR10-shaped synthetic randn(B,3,32,32), ConvolForwardNet student (22 tensors, 1.00 M '
+                     'params) distilled from the 5.3 M teacher, KD loss T=2, SGD nesterov, 4-bit uniform, bucket 256, STE',
+           'per_gpu_batch': per_gpu_batch, 'global_batch': per_gpu_batch * n_gpus, 'steps': steps, 'warmup': warmup}
+    for mode in ('multi_graph', 'multi', 'per_tensor'):
+        tr = DistillTrainer(models.student(), models.teacher(), dev, num_bits=4, bucket_size=256,
+                            mode='multi' if mode == 'multi_graph' else mode)
+        batches = [synthetic_batch(per_gpu_batch, dev, seed=1000 * rank + i) for i in range(4)]
+        if mode == 'multi_graph':
+            try:
+                tr.capture(*batches[0])
+            except Exception as e:                         # noqa: BLE001 -- report, do not hide
+                out[mode] = {'error': 'graph capture failed: %r' % (e,)}
+                del tr
+                continue
+        for i in range(warmup):
+            tr.step(*batches[i % 4])
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.step(*batches[i % 4])
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        # per-phase breakdown (each phase bracketed by synchronize; serialised, so the sum exceeds the step)
+        phases = {}
+        def timed(name, fn, reps=20):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            phases[name] = round((time.perf_counter() - a) / reps * 1e3, 4)
+        x, y = batches[0]
+        timed('quantize_ms', tr.quantize)
+        timed('fwd_bwd_ms', lambda: tr.forward_backward(x, y))
+        timed('restore_ms', tr.restore)
+        timed('allreduce_ms', tr.sync.sync)
+        timed('optimizer_ms', tr.opt.step)
+        out[mode] = {'steps_per_sec': round(steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
+                     'samples_per_sec': round(steps * per_gpu_batch * n_gpus / dt, 1), 'phases': phases}
+        del tr
+    out['note'] = ("'multi' = one multi-tensor quantize launch per step on persistent shadows (K9); 'multi_graph' = the "
+                   "same step replayed from two hipGraphs (quantize+fwd+bwd | SGD) with the all-reduce between them; "
+                   "'per_tensor' = the reference's loop shape (22 uniformQuantization calls + restore)")
+    return out
+
+
 def load_pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -111,6 +176,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-distill', action='store_true', help='skip the distilled-training steps/sec leg')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
     args = ap.parse_args()
 
@@ -206,6 +272,12 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(x_host)
 
+    distill = None
+    if not args.no_distill:
+        del live[:], xs[1:]
+        torch.cuda.empty_cache()
+        distill = distill_steps_per_sec(dev, rank, n_gpus, distributed)
+
     if rank == 0:
         bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM
         total_bytes = bytes_per_launch * args.steps * n_gpus
@@ -234,6 +306,7 @@ def main():
                 'copy_ceiling_GBps': round(copy_gbps, 1),
             },
             'cpu_baseline': cpu,
+            'distill': distill,
             'parity_bit_exact_vs_oracle': parity,
             'device': torch.cuda.get_device_name(dev),
         }

@@ -1,0 +1,146 @@
+"""One quantized-distillation training step, MI355X-native.
+
+Restates the reference's hot loop (ref: cnn_models/conv_forward_model.py:280-317 with
+cnn_models/help_fun.py:60-158) for torch 2.x:
+
+    reference, per step                                  here, per step
+    ---------------------------------------------------  -----------------------------------------
+    state_dict(); for p: p.data = uniformQuantization()   ONE multi-tensor launch: masters -> shadows
+    zero_grad; student fwd; teacher fwd; KD loss; bwd      same (grads land in one flat buffer)
+    load_state_dict(saved)  (copy masters back)            nothing: the model computes on the shadows,
+                                                           the masters were never overwritten
+    [nn.DataParallel reduce/broadcast]                     ONE RCCL all-reduce of the flat gradient
+    optimizer.step() on the full-precision weights         SGD (nesterov) on the flat master buffer
+
+The straight-through estimator is the wiring itself: gradients are taken at the quantized point
+and applied to the full-precision masters.  mode='per_tensor' keeps the reference's structure
+(per-parameter API calls + save/restore) for comparison.
+"""
+import torch
+
+import quantization
+from quantized_distillation_amd.multi_tensor import MultiTensorQuantizer
+
+from . import models
+from .flat import FlatLayout, GradSynchronizer
+
+
+class DistillTrainer(object):
+    def __init__(self, student, teacher, device, num_bits=4, bucket_size=256, lr=1e-3, momentum=0.9,
+                 weight_decay=2.2e-4, nesterov=True, quantize_first_and_last_layer=True, mode='multi',
+                 backprop_quantization_style='none', grad_chunks=1):
+        self.device = device
+        self.student = student.to(device).train()
+        self.teacher = teacher.to(device).eval()
+        for p in self.teacher.parameters():
+            p.requires_grad_(False)
+        self.s = 2 ** num_bits                                   # ref: conv_forward_model.py:209-211
+        self.bucket_size = bucket_size
+        self.mode = mode
+        self.style = backprop_quantization_style
+        params = list(self.student.parameters())
+        self.params = params
+        n = len(params)
+        self.quantized = [not (not quantize_first_and_last_layer and (i == 0 or i == n - 1)) for i in range(n)]
+        layout = FlatLayout([p.shape for p in params])
+        self.layout = layout
+        self.flat_master = torch.zeros(layout.total, device=device)
+        self.flat_grad = torch.zeros(layout.total, device=device)
+        self.masters = layout.views(self.flat_master)
+        grads = layout.views(self.flat_grad)
+        for m, p in zip(self.masters, params):
+            m.copy_(p.data)
+        if mode == 'multi':
+            self.flat_shadow = torch.zeros(layout.total, device=device)
+            shadows = layout.views(self.flat_shadow)
+            for i, p in enumerate(params):
+                # the model computes on the shadow (or straight on the master when not quantized)
+                p.data = shadows[i] if self.quantized[i] else self.masters[i]
+            qi = [i for i in range(n) if self.quantized[i]]
+            self.mt = MultiTensorQuantizer([self.masters[i] for i in qi], self.s, bucket_size,
+                                           outputs=[shadows[i] for i in qi])
+        else:
+            for i, p in enumerate(params):
+                p.data = self.masters[i]
+        for g, p in zip(grads, params):
+            p.grad = g
+        self.flat_master.grad = self.flat_grad
+        self.opt = torch.optim.SGD([self.flat_master], lr=lr, momentum=momentum, nesterov=nesterov,
+                                   weight_decay=weight_decay)
+        self.sync = GradSynchronizer(self.flat_grad, chunks=grad_chunks)
+
+    # ------------------------------------------------------------------ pieces of a step
+    def quantize(self):
+        if self.mode == 'multi':
+            if self.style == 'truncated':
+                self.flat_master.clamp_(-1, 1)                   # ref: :240-241
+            self.mt.quantize(check_pointers=False)
+        else:                                                    # the reference's loop shape, :235-247
+            for i, p in enumerate(self.params):
+                if self.quantized[i]:
+                    p.data = quantization.uniformQuantization(self.masters[i], self.s, bucket_size=self.bucket_size)[0]
+
+    def restore(self):
+        if self.mode != 'multi':                                 # ref: :302 load_state_dict
+            for i, p in enumerate(self.params):
+                p.data = self.masters[i]
+
+    def forward_backward(self, images, labels):
+        self.flat_grad.zero_()
+        out = self.student(images)
+        with torch.no_grad():
+            t_out = self.teacher(images)
+        loss = models.kd_loss(out, t_out, labels)
+        loss.backward()
+        return loss
+
+    def step(self, images, labels):
+        if self._graph_fb is not None:
+            return self._step_graph(images, labels)
+        self.quantize()
+        loss = self.forward_backward(images, labels)
+        self.restore()
+        self.sync.sync()
+        self.opt.step()
+        return loss
+
+    # ------------------------------------------------------------------ hipGraph replay of the step
+    _graph_fb = None
+
+    def capture(self, images, labels, warmup=3):
+        """Capture the launch-bound part of the step in hipGraphs (torch.cuda.CUDAGraph): graph A =
+        multi-tensor quantize + student/teacher forward + KD loss + backward, graph B = the SGD
+        update.  The gradient all-reduce stays between the two replays (eager RCCL call), so the
+        distributed step is  A.replay(); all_reduce; B.replay().  Only for mode='multi'."""
+        assert self.mode == 'multi', 'graph capture needs the persistent-shadow (multi) mode'
+        self._sx, self._sy = images.clone(), labels.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                      # materialises momentum buffers, cudnn/miopen plans
+                self.quantize()
+                self.forward_backward(self._sx, self._sy)
+                self.opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self.quantize()
+            self._sloss = self.forward_backward(self._sx, self._sy)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self.opt.step()
+        self._graph_fb, self._graph_opt = ga, gb
+
+    def _step_graph(self, images, labels):
+        self._sx.copy_(images, non_blocking=True)
+        self._sy.copy_(labels, non_blocking=True)
+        self._graph_fb.replay()
+        self.sync.sync()
+        self._graph_opt.replay()
+        return self._sloss
+
+
+def synthetic_batch(batch, device, seed=0, classes=10, side=32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(batch, 3, side, side, generator=g).to(device),
+            torch.randint(0, classes, (batch,), generator=g).to(device))

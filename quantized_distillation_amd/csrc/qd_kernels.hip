@@ -135,8 +135,8 @@ __device__ __forceinline__ void store_side4(const KParams& p, int64_t e, const f
             if (p.idx_bytes == 8) {
                 l2* o = (l2*)((int64_t*)p.idx + e);
                 l2 a = {(int64_t)s[0], (int64_t)s[1]}, b = {(int64_t)s[2], (int64_t)s[3]};
-                __builtin_nontemporal_store(a, o);
-                __builtin_nontemporal_store(b, o + 1);
+                o[0] = a;      // plain stores: the two 16-byte halves of a lane's 32 B merge in L2
+                o[1] = b;
             } else {
                 const uint32_t pk = (uint32_t)(int)s[0] | ((uint32_t)(int)s[1] << 8) |
                                     ((uint32_t)(int)s[2] << 16) | ((uint32_t)(int)s[3] << 24);
@@ -146,22 +146,24 @@ __device__ __forceinline__ void store_side4(const KParams& p, int64_t e, const f
     }
 }
 
-// ---- 16 lanes (one DPP row) process one arbitrary bucket [lo, hi): scalar accesses, two passes
-// (the second pass re-reads from L1/L2).  Used for the ragged last bucket, short buckets and
-// the multi-tensor kernel's unaligned cases.  `l` = lane index inside the row (0..15).
-template <int MODE>
-__device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable* T, int64_t bkt, int64_t lo,
+// ---- LANES lanes (16 = one DPP row, 64 = a wave) process one arbitrary bucket [lo, hi): scalar
+// accesses, two passes (the second pass re-reads from L1/L2).  Used for the ragged last bucket,
+// short buckets, odd bucket sizes and the multi-tensor kernel's unaligned cases.
+// `l` = lane index inside the group (0..LANES-1).
+template <int MODE, int LANES>
+__device__ __forceinline__ void bucket_lanes(const KParams& p, const PointTable* T, int64_t bkt, int64_t lo,
                                              int64_t hi, int l, const Prep& pp) {
     float a, b;
     if (MODE == MODE_NEAREST && p.prescaled) {
         a = p.alpha[bkt]; b = p.beta[bkt];
     } else {
         float mn = INFINITY, mx = -INFINITY;
-        for (int64_t i = lo + l; i < hi; i += 16) {
+        for (int64_t i = lo + l; i < hi; i += LANES) {
             const float v = prep(p.x[i], pp);
             mn = fminf(mn, v); mx = fmaxf(mx, v);
         }
-        mn = row16_min(mn); mx = row16_max(mx);
+        if (LANES == 16) { mn = row16_min(mn); mx = row16_max(mx); }
+        else { mn = wave_min(mn); mx = wave_max(mx); }
         alpha_beta(mn, mx, a, b);
         if (l == 0) {
             if (p.alpha) p.alpha[bkt] = a;
@@ -169,7 +171,7 @@ __device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable*
         }
     }
     float last = 0.0f;
-    for (int64_t i = lo + l; i < hi; i += 16) {
+    for (int64_t i = lo + l; i < hi; i += LANES) {
         float v = p.x[i];
         if (!(MODE == MODE_NEAREST && p.prescaled)) v = prep(v, pp);
         float rnd = 0.0f;
@@ -189,81 +191,98 @@ __device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable*
         const int64_t end = lo + p.row;
         if (hi < end && hi == p.n && p.nb > 1) {
             const float u_last = transform<MODE>(p, T, prep(p.x[p.n - 1], pp), a, b, pp.mean, 0.0f, last);
-            for (int64_t i = hi + l; i < end; i += 16) p.out[i] = u_last;
+            for (int64_t i = hi + l; i < end; i += LANES) p.out[i] = u_last;
         }
     }
 }
 
+template <int MODE>
+__device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable* T, int64_t bkt, int64_t lo,
+                                             int64_t hi, int l, const Prep& pp) {
+    bucket_lanes<MODE, 16>(p, T, bkt, lo, hi, l, pp);
+}
+
 // ---- vector path: LPB lanes per bucket, V float4 per lane: bucket = LPB*V*4 elements ---------
-// LPB == 16: a DPP row owns a bucket, a wave handles 4 buckets per iteration.
-// LPB == 64: the whole wave owns a bucket (large buckets).
-template <int MODE, int LPB, int V>
+// LPB == 16: a DPP row owns a bucket; LPB == 64: the whole wave owns a bucket (large buckets).
+// U = consecutive buckets each lane group handles per tile, so that a wave always streams 4 KiB
+// per tile (U*V == 4 float4 per lane in flight) whatever the bucket size.
+template <int MODE, int LPB, int V, int U>
 __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     __shared__ PointTable Ts;
     const PointTable* T = nullptr;
     if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
 
-    constexpr int BPW = 64 / LPB;                 // buckets per wave iteration
+    constexpr int BPW = (64 / LPB) * U;           // buckets per wave tile
     constexpr int ROW = LPB * V * 4;              // elements per bucket
     const int lane = threadIdx.x & 63;
-    const int sub = lane / LPB;                   // which bucket of the wave tile
+    const int sub = lane / LPB;                   // which lane group of the wave
     const int l = lane % LPB;                     // lane inside the bucket
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
+    const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t ntiles = (p.nvec + BPW - 1) / BPW;
 
     for (int64_t t = wave; t < ntiles; t += nwaves) {
-        const int64_t bkt = t * BPW + sub;
-        if (bkt < p.nvec) {
-            const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
-            const f4* src = (const f4*)(p.x + e0);
-            f4 v[V];
+        const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
+        f4 v[U][V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * LPB);
-            float a, b;
-            if (MODE == MODE_NEAREST && p.prescaled) {
-                a = p.alpha[bkt]; b = p.beta[bkt];
-            } else {
+        for (int uu = 0; uu < U; ++uu) {
+            if (bkt0 + uu < p.nvec) {
+                const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
 #pragma unroll
-                for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
-                float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
-                float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
-#pragma unroll
-                for (int j = 1; j < V; ++j) {
-                    mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
-                    mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
-                }
-                if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
-                else { mn = wave_min(mn); mx = wave_max(mx); }
-                alpha_beta(mn, mx, a, b);
-                if (l == 0) {
-                    if (p.alpha) p.alpha[bkt] = a;
-                    if (p.beta) p.beta[bkt] = b;
-                }
+                for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
             }
-            f4* dst = (f4*)(p.out + e0);
+        }
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const int64_t e = e0 + (int64_t)j * LPB * 4;
-                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
-                float side[4];
-                f4 r;
-                r.x = transform<MODE>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0]);
-                r.y = transform<MODE>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1]);
-                r.z = transform<MODE>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2]);
-                r.w = transform<MODE>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3]);
-                __builtin_nontemporal_store(r, dst + j * LPB);
-                store_side4<MODE>(p, e, side);
+        for (int uu = 0; uu < U; ++uu) {
+            const int64_t bkt = bkt0 + uu;
+            if (bkt < p.nvec) {
+                const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
+                float a, b;
+                if (prescaled) {
+                    a = p.alpha[bkt]; b = p.beta[bkt];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
+                    float mn = fminf(fminf(v[uu][0].x, v[uu][0].y), fminf(v[uu][0].z, v[uu][0].w));
+                    float mx = fmaxf(fmaxf(v[uu][0].x, v[uu][0].y), fmaxf(v[uu][0].z, v[uu][0].w));
+#pragma unroll
+                    for (int j = 1; j < V; ++j) {
+                        mn = fminf(mn, fminf(fminf(v[uu][j].x, v[uu][j].y), fminf(v[uu][j].z, v[uu][j].w)));
+                        mx = fmaxf(mx, fmaxf(fmaxf(v[uu][j].x, v[uu][j].y), fmaxf(v[uu][j].z, v[uu][j].w)));
+                    }
+                    if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
+                    else { mn = wave_min(mn); mx = wave_max(mx); }
+                    alpha_beta(mn, mx, a, b);
+                    if (l == 0) {
+                        if (p.alpha) p.alpha[bkt] = a;
+                        if (p.beta) p.beta[bkt] = b;
+                    }
+                }
+                f4* dst = (f4*)(p.out + e0);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const int64_t e = e0 + (int64_t)j * LPB * 4;
+                    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                    float side[4];
+                    f4 r;
+                    r.x = transform<MODE>(p, T, v[uu][j].x, a, b, pp.mean, rnd[0], side[0]);
+                    r.y = transform<MODE>(p, T, v[uu][j].y, a, b, pp.mean, rnd[1], side[1]);
+                    r.z = transform<MODE>(p, T, v[uu][j].z, a, b, pp.mean, rnd[2], side[2]);
+                    r.w = transform<MODE>(p, T, v[uu][j].w, a, b, pp.mean, rnd[3], side[3]);
+                    __builtin_nontemporal_store(r, dst + j * LPB);
+                    store_side4<MODE>(p, e, side);
+                }
             }
         }
     }
 
-    // buckets after the vector part (the ragged last bucket): one DPP row each, extra block
+    // buckets after the vector part (the ragged last bucket): one DPP row each, last block
     if (blockIdx.x == gridDim.x - 1) {
         const int row_id = threadIdx.x >> 4;                  // 16 rows per 256-thread block
         for (int64_t bkt = p.nvec + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
@@ -274,7 +293,27 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     }
 }
 
-// ---- generic path: one block per bucket, any row length / alignment --------------------------
+// ---- generic path, small/medium rows: one lane group (16 lanes or a wave) per bucket, 256-thread
+// blocks, no LDS, no barrier.  Any row length / alignment.
+template <int MODE, int LANES>
+__global__ __launch_bounds__(256) void k_bucket_groups(KParams p) {
+    __shared__ PointTable Ts;
+    const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / LANES;
+    const int l = threadIdx.x % LANES;
+    for (int64_t bkt = group; bkt < p.nb; bkt += ngroups) {
+        const int64_t lo = bkt * p.row;
+        const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+        bucket_lanes<MODE, LANES>(p, T, bkt, lo, hi, l, pp);
+    }
+}
+
+// ---- generic path, huge rows: one block per bucket, any row length / alignment ----------------
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_bucket_generic(KParams p) {
     __shared__ PointTable Ts;
@@ -575,39 +614,94 @@ __global__ __launch_bounds__(256) void k_arg_final(const float* pv, const int64_
 // stage 1: every block accumulates sum_{idx==j} g*alpha over its slice into k bins.
 // KR > 0: bins live in registers (k <= KR, fully unrolled select-accumulate, deterministic);
 // KR == 0: bins live in LDS, one private set per wave (k <= kMaxPoints).
+// 16-byte g loads + packed 4-byte (uint8 x4) or 2 x 16-byte (int64 x4) index loads; the bucket of
+// an element is a shift when the bucket size is a power of two (no integer division per element).
+template <int KR>
+struct PgAcc {
+    float acc[KR > 0 ? KR : 1];
+    float* lds;
+    __device__ __forceinline__ void init(float* wave_bins) {
+        lds = wave_bins;
+#pragma unroll
+        for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] = 0.0f;
+    }
+    __device__ __forceinline__ void add(int id, float m) {
+        if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < KR; ++j) acc[j] += (id == j) ? m : 0.0f;
+        } else {
+            atomicAdd(&lds[id], m);                       // LDS atomic on wave-private bins
+        }
+    }
+};
+
 template <int KR>
 __global__ __launch_bounds__(256) void k_point_grad_partial(const float* g, const void* idx, int idx_bytes,
                                                             const float* alpha, int64_t n, int64_t row, int64_t nb,
-                                                            int k, float* part /* [grid][k] */) {
+                                                            int row_shift, int k, float* part /* [grid][k] */) {
     __shared__ float bins[KR > 0 ? 4 * 16 : 4 * kMaxPoints];
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int stride = KR > 0 ? 16 : kMaxPoints;
-    if (KR > 0) {
-        float acc[KR > 0 ? KR : 1];
-#pragma unroll
-        for (int j = 0; j < KR; ++j) acc[j] = 0.0f;
-        for (int64_t i = tid; i < n; i += nth) {
-            const int64_t bkt = nb == 1 ? 0 : i / row;
-            const float m = g[i] * alpha[bkt];       // one fp32 multiply, :495
-            const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
-#pragma unroll
-            for (int j = 0; j < KR; ++j) acc[j] += (id == j) ? m : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < KR; ++j) {
-            const float s = wave_sum(acc[j]);
-            if (lane == 0) bins[w * stride + j] = s;
-        }
-    } else {
+    if (KR == 0) {
         for (int j = lane; j < k; j += 64) bins[w * stride + j] = 0.0f;
         __syncthreads();
-        for (int64_t i = tid; i < n; i += nth) {
-            const int64_t bkt = nb == 1 ? 0 : i / row;
-            const float m = g[i] * alpha[bkt];
-            const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
-            atomicAdd(&bins[w * stride + id], m);    // LDS atomic, wave-private bins
+    }
+    PgAcc<KR> A;
+    A.init(bins + w * stride);
+    const bool small = n < (int64_t)0xFFFFFFFFll;
+    auto bucket_of = [&](int64_t e) -> int64_t {
+        if (nb == 1) return 0;
+        if (row_shift >= 0) return e >> row_shift;
+        return small ? (int64_t)((uint32_t)e / (uint32_t)row) : e / row;
+    };
+    const bool idx_ok = idx_bytes == 8 ? ((((uintptr_t)idx) & 15) == 0) : ((((uintptr_t)idx) & 3) == 0);
+    const bool vec = ((((uintptr_t)g) & 15) == 0) && idx_ok && (nb == 1 || (row & 3) == 0);
+    int64_t done = 0;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        auto load_idx = [&](int64_t i, int& i0, int& i1, int& i2, int& i3) {
+            if (idx_bytes == 8) {
+                const l2 p0 = __builtin_nontemporal_load((const l2*)idx + 2 * i);
+                const l2 p1 = __builtin_nontemporal_load((const l2*)idx + 2 * i + 1);
+                i0 = (int)p0.x; i1 = (int)p0.y; i2 = (int)p1.x; i3 = (int)p1.y;
+            } else {
+                const uint32_t pk = __builtin_nontemporal_load((const uint32_t*)idx + i);
+                i0 = pk & 255; i1 = (pk >> 8) & 255; i2 = (pk >> 16) & 255; i3 = pk >> 24;
+            }
+        };
+        int64_t i = tid;
+        for (; i + nth < n4; i += 2 * nth) {              // two independent float4 in flight per lane
+            const int64_t i2 = i + nth;
+            const f4 ga = __builtin_nontemporal_load((const f4*)g + i);
+            const f4 gb = __builtin_nontemporal_load((const f4*)g + i2);
+            int a0, a1, a2, a3, b0, b1, b2, b3;
+            load_idx(i, a0, a1, a2, a3);
+            load_idx(i2, b0, b1, b2, b3);
+            const float sa = alpha[bucket_of(i << 2)], sb = alpha[bucket_of(i2 << 2)];
+            A.add(a0, ga.x * sa); A.add(a1, ga.y * sa); A.add(a2, ga.z * sa); A.add(a3, ga.w * sa);   // one fp32 multiply each, :495
+            A.add(b0, gb.x * sb); A.add(b1, gb.y * sb); A.add(b2, gb.z * sb); A.add(b3, gb.w * sb);
+        }
+        for (; i < n4; i += nth) {
+            const f4 ga = __builtin_nontemporal_load((const f4*)g + i);
+            int a0, a1, a2, a3;
+            load_idx(i, a0, a1, a2, a3);
+            const float sa = alpha[bucket_of(i << 2)];
+            A.add(a0, ga.x * sa); A.add(a1, ga.y * sa); A.add(a2, ga.z * sa); A.add(a3, ga.w * sa);
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nth) {
+        const float m = g[i] * alpha[bucket_of(i)];
+        const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
+        A.add(id, m);
+    }
+    if (KR > 0) {
+#pragma unroll
+        for (int j = 0; j < (KR > 0 ? KR : 1); ++j) {
+            const float sum = wave_sum(A.acc[j]);
+            if (lane == 0) bins[w * stride + j] = sum;
         }
     }
     __syncthreads();
@@ -615,22 +709,114 @@ __global__ __launch_bounds__(256) void k_point_grad_partial(const float* g, cons
         part[(int64_t)blockIdx.x * k + j] =
             (bins[j] + bins[stride + j]) + (bins[2 * stride + j] + bins[3 * stride + j]);
 }
-// stage 2: fixed-order fold of the per-block partials, float64 accumulation
+// stage 2: fold of the per-block partials in a fixed order (thread t sums rows t, t+256, ... in
+// float64, then a fixed shuffle/LDS tree), so the result is reproducible run to run
 __global__ __launch_bounds__(256) void k_point_grad_final(const float* part, int nblocks, int k, float* out) {
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int j = 0; j < k; ++j) {
         double acc = 0.0;
-        for (int b = 0; b < nblocks; ++b) acc += (double)part[(int64_t)b * k + j];
-        out[j] = (float)acc;
+        for (int b = threadIdx.x; b < nblocks; b += 256) acc += (double)part[(int64_t)b * k + j];
+        acc = wave_sum_d(acc);
+        __syncthreads();
+        if (lane == 0) red[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) out[j] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// ---- K7 (vector path): the whole bucket lives in registers (x, g, q as float4), one pass ------
+// LPB lanes per bucket, V float4 per lane, as in k_bucket_vec.  Index ties: the FIRST element (in
+// memory order) at the top / bottom level of the quantized bucket (or the true arg of x).
+template <int LPB, int V>
+__global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const float* g, float* out, int64_t nvec,
+                                                          float sm1, int tie_mode) {
+    constexpr int BPW = 64 / LPB;
+    constexpr int ROW = LPB * V * 4;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPB, l = lane % LPB;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ntiles = (nvec + BPW - 1) / BPW;
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+        const int64_t bkt = t * BPW + sub;
+        if (bkt >= nvec) continue;
+        const int64_t e0 = bkt * ROW + (int64_t)l * 4;
+        f4 xv[V], gv[V], qv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            xv[j] = __builtin_nontemporal_load((const f4*)(x + e0) + j * LPB);
+            gv[j] = __builtin_nontemporal_load((const f4*)(g + e0) + j * LPB);
+        }
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            mn = fminf(mn, fminf(fminf(xv[j].x, xv[j].y), fminf(xv[j].z, xv[j].w)));
+            mx = fmaxf(mx, fmaxf(fmaxf(xv[j].x, xv[j].y), fmaxf(xv[j].z, xv[j].w)));
+        }
+        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); } else { mn = wave_min(mn); mx = wave_max(mx); }
+        float a, b, lev;
+        alpha_beta(mn, mx, a, b);
+        float qmn = INFINITY, qmx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            qv[j].x = qdq(xv[j].x, a, b, sm1, 0.0f, lev); qv[j].y = qdq(xv[j].y, a, b, sm1, 0.0f, lev);
+            qv[j].z = qdq(xv[j].z, a, b, sm1, 0.0f, lev); qv[j].w = qdq(xv[j].w, a, b, sm1, 0.0f, lev);
+            qmn = fminf(qmn, fminf(fminf(qv[j].x, qv[j].y), fminf(qv[j].z, qv[j].w)));
+            qmx = fmaxf(qmx, fmaxf(fmaxf(qv[j].x, qv[j].y), fmaxf(qv[j].z, qv[j].w)));
+        }
+        if (LPB == 16) { qmn = row16_min(qmn); qmx = row16_max(qmx); } else { qmn = wave_min(qmn); qmx = wave_max(qmx); }
+        float aq, bq;
+        alpha_beta(qmn, qmx, aq, bq);                       // scale_down of the QUANTIZED bucket, :350
+        float sum = 0.0f;
+        int jmax = 0x7fffffff, jmin = 0x7fffffff;           // index inside the bucket
+        const bool ref_tie = tie_mode == QD_STE_TIE_REFERENCE;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int base = (j * LPB + l) * 4;
+#define QD_STE_ELEM(c, off)                                                          \
+            {                                                                        \
+                float qs = qv[j].c - bq;  qs = qs / aq;                              \
+                float u = xv[j].c - bq;   u = u / aq;                                \
+                const float d = qs - u;                                              \
+                sum += gv[j].c * d;                                                  \
+                const bool top = ref_tie ? (qv[j].c == qmx) : (xv[j].c == mx);       \
+                const bool bot = ref_tie ? (qv[j].c == qmn) : (xv[j].c == mn);       \
+                jmax = (top && base + off < jmax) ? base + off : jmax;               \
+                jmin = (bot && base + off < jmin) ? base + off : jmin;               \
+            }
+            QD_STE_ELEM(x, 0) QD_STE_ELEM(y, 1) QD_STE_ELEM(z, 2) QD_STE_ELEM(w, 3)
+#undef QD_STE_ELEM
+        }
+        if (LPB == 16) { sum = row16_sum(sum); jmax = row16_imin(jmax); jmin = row16_imin(jmin); }
+        else {
+            sum = wave_sum(sum);
+            jmax = row16_imin(jmax); jmax = min(jmax, __shfl_xor(jmax, 16)); jmax = min(jmax, __shfl_xor(jmax, 32));
+            jmin = row16_imin(jmin); jmin = min(jmin, __shfl_xor(jmin, 16)); jmin = min(jmin, __shfl_xor(jmin, 32));
+        }
+        const bool touch = jmax != jmin;                    // constant bucket: +S and -S cancel
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int base = (j * LPB + l) * 4;
+            f4 o = gv[j];
+            if (touch) {
+                if (base + 0 == jmax) o.x = o.x + sum;  if (base + 0 == jmin) o.x = o.x - sum;
+                if (base + 1 == jmax) o.y = o.y + sum;  if (base + 1 == jmin) o.y = o.y - sum;
+                if (base + 2 == jmax) o.z = o.z + sum;  if (base + 2 == jmin) o.z = o.z - sum;
+                if (base + 3 == jmax) o.w = o.w + sum;  if (base + 3 == jmin) o.w = o.w - sum;
+            }
+            __builtin_nontemporal_store(o, (f4*)(out + e0) + j * LPB);
+        }
     }
 }
 
 // ---- K7: 'complicated' STE backward, one wave per bucket --------------------------------------
 __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const float* g, float* out, int64_t n,
-                                                      int64_t row, int64_t nb, float sm1, int tie_mode) {
+                                                      int64_t row, int64_t first, int64_t nb, float sm1, int tie_mode) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t bkt = wave; bkt < nb; bkt += nwaves) {
+    for (int64_t bkt = first + wave; bkt < nb; bkt += nwaves) {
         const int64_t lo = bkt * row;
         const int64_t hi = lo + row < n ? lo + row : n;
         // pass 1: alpha/beta of x
@@ -684,17 +870,46 @@ __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const floa
 __global__ __launch_bounds__(256) void k_clamp(float* w, int64_t n, float limit) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid; i < n; i += nth) {
+    int64_t done = 0;
+    if ((((uintptr_t)w) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nth) {
+            f4 v = ((f4*)w)[i];
+            f4 r;
+            r.x = v.x > limit ? limit : (v.x < -limit ? -limit : v.x);
+            r.y = v.y > limit ? limit : (v.y < -limit ? -limit : v.y);
+            r.z = v.z > limit ? limit : (v.z < -limit ? -limit : v.z);
+            r.w = v.w > limit ? limit : (v.w < -limit ? -limit : v.w);
+            if (r.x != v.x || r.y != v.y || r.z != v.z || r.w != v.w) ((f4*)w)[i] = r;   // write only what changes
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nth) {
         float v = w[i];
         v = v > limit ? limit : v;
         v = v < -limit ? -limit : v;
         w[i] = v;
     }
 }
+// grad[|w| > limit] = 0: reads w (4 B) and touches grad only where the mask hits
 __global__ __launch_bounds__(256) void k_truncated_ste(const float* w, float* grad, int64_t n, float limit) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid; i < n; i += nth)
+    int64_t done = 0;
+    if ((((uintptr_t)w | (uintptr_t)grad) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nth) {
+            const f4 v = __builtin_nontemporal_load((const f4*)w + i);
+            const bool m0 = fabsf(v.x) > limit, m1 = fabsf(v.y) > limit, m2 = fabsf(v.z) > limit, m3 = fabsf(v.w) > limit;
+            if (m0 | m1 | m2 | m3) {                      // one 16-byte read-modify-write instead of 4-byte pokes
+                f4 gv = ((const f4*)grad)[i];
+                gv.x = m0 ? 0.0f : gv.x; gv.y = m1 ? 0.0f : gv.y; gv.z = m2 ? 0.0f : gv.z; gv.w = m3 ? 0.0f : gv.w;
+                ((f4*)grad)[i] = gv;
+            }
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nth)
         if (fabsf(w[i]) > limit) grad[i] = 0.0f;
 }
 
@@ -736,7 +951,7 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* table
             const f4* src = (const f4*)(p.x + lo) + l;
             f4 v[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) v[j] = src[j * 16];
+            for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * 16);   // masters: read once
             float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
             float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
 #pragma unroll
@@ -822,30 +1037,35 @@ int launch_bucketed(KParams& p, hipStream_t st) {
                          (MODE != MODE_NEAREST || p.idx == nullptr || p.idx_bytes != 8 || (((uintptr_t)p.idx) & 15) == 0) &&
                          (MODE != MODE_QDQ || p.lev8 == nullptr || (((uintptr_t)p.lev8) & 3) == 0);
     const int64_t nfull = p.n / p.row;                 // leading full buckets
-#define QD_VEC(LPB, V)                                                                        \
-    {                                                                                         \
-        p.nvec = nfull;                                                                       \
-        const int64_t tiles = (nfull + (64 / LPB) - 1) / (64 / LPB);                          \
-        const int blocks = blocks_for(tiles, 4) + 1; /* +1: the block that owns the tail */   \
-        hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V>), dim3(blocks), dim3(256), 0, st, p);  \
-        return check_launch();                                                                \
+#define QD_VEC(LPB, V, U)                                                                       \
+    {                                                                                           \
+        p.nvec = nfull;                                                                         \
+        constexpr int64_t bpw = (64 / LPB) * U;                                                 \
+        const int64_t tiles = (nfull + bpw - 1) / bpw;                                          \
+        const int blocks = blocks_for(tiles, 4) + 1; /* +1: the block that owns the tail */     \
+        hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V, U>), dim3(blocks), dim3(256), 0, st, p); \
+        return check_launch();                                                                  \
     }
     if (aligned && p.nb > 1) {
         switch (p.row) {
-            case 64: QD_VEC(16, 1)
-            case 128: QD_VEC(16, 2)
-            case 256: QD_VEC(16, 4)
-            case 512: QD_VEC(64, 2)
-            case 1024: QD_VEC(64, 4)
-            case 2048: QD_VEC(64, 8)
+            case 64: QD_VEC(16, 1, 4)
+            case 128: QD_VEC(16, 2, 2)
+            case 256: QD_VEC(16, 4, 1)
+            case 512: QD_VEC(64, 2, 2)
+            case 1024: QD_VEC(64, 4, 1)
+            case 2048: QD_VEC(64, 8, 1)
             default: break;
         }
     }
 #undef QD_VEC
     p.nvec = 0;
-    const int threads = p.row <= 64 ? 64 : p.row <= 256 ? 128 : p.row <= 4096 ? 256 : 1024;
-    const int blocks = blocks_for(p.nb, 1);
-    hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(blocks), dim3(threads), 0, st, p);
+    if (p.row <= 48) {                                   // 16 buckets per block
+        hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16)), dim3(256), 0, st, p);
+    } else if (p.row <= 16384) {                         // 4 buckets per block, one wave each
+        hipLaunchKernelGGL((k_bucket_groups<MODE, 64>), dim3(blocks_for(p.nb, 4)), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(blocks_for(p.nb, 1)), dim3(1024), 0, st, p);
+    }
     return check_launch();
 }
 
@@ -1016,10 +1236,16 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     hipStream_t st = (hipStream_t)stream;
     int64_t nb, row;
     geometry(n > 0 ? n : 1, bucket, nb, row);
-    int blocks = blocks_for(n, 256 * 8);
-    if (blocks > kPartialBlocks) blocks = kPartialBlocks;
+    // partial rows of k floats each must fit the workspace's [kPartialBlocks * kMaxPoints] floats
+    int blocks = blocks_for(n, 256 * 4 * 4);
+    const int64_t max_rows = (int64_t)kPartialBlocks * kMaxPoints / k;
+    const int64_t cap = k <= 16 ? 8192 : 2048;
+    if (blocks > cap) blocks = (int)cap;
+    if (blocks > max_rows) blocks = (int)max_rows;
+    int row_shift = -1;
+    if (nb > 1 && (row & (row - 1)) == 0) { row_shift = 0; while (((int64_t)1 << row_shift) < row) ++row_shift; }
 #define QD_PG(KR) hipLaunchKernelGGL((k_point_grad_partial<KR>), dim3(blocks), dim3(256), 0, st, g, idx, idx_bytes, \
-                                     alpha, n, row, nb, k, w.pg_part)
+                                     alpha, n, row, nb, row_shift, k, w.pg_part)
     if (k <= 4) QD_PG(4);
     else if (k <= 8) QD_PG(8);
     else if (k <= 16) QD_PG(16);
@@ -1036,23 +1262,43 @@ int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64
     if (n == 0) return 0;
     int64_t nb, row;
     geometry(n, bucket, nb, row);
-    const int blocks = blocks_for(nb, 4);
-    hipLaunchKernelGGL(k_ste_backward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, g, out, n, row, nb,
-                       (float)(levels - 1), tie_mode);
+    hipStream_t st = (hipStream_t)stream;
+    const float sm1 = (float)(levels - 1);
+    int64_t first = 0;                                   // buckets [0, first) take the register path
+    const bool aligned = (((((uintptr_t)x) | ((uintptr_t)g) | ((uintptr_t)out)) & 15) == 0) && nb > 1;
+    const int64_t nfull = n / row;
+#define QD_STE(LPB, V)                                                                                   \
+    {                                                                                                    \
+        first = nfull;                                                                                   \
+        const int64_t tiles = (nfull + (64 / LPB) - 1) / (64 / LPB);                                     \
+        hipLaunchKernelGGL((k_ste_backward_vec<LPB, V>), dim3(blocks_for(tiles, 4)), dim3(256), 0, st, x, g, \
+                           out, nfull, sm1, tie_mode);                                                   \
+    }
+    if (aligned && nfull > 0) {
+        if (row == 64) QD_STE(16, 1)
+        else if (row == 128) QD_STE(16, 2)
+        else if (row == 256) QD_STE(16, 4)
+        else if (row == 512) QD_STE(64, 2)
+        else if (row == 1024) QD_STE(64, 4)
+    }
+#undef QD_STE
+    if (first < nb)
+        hipLaunchKernelGGL(k_ste_backward, dim3(blocks_for(nb - first, 4)), dim3(256), 0, st, x, g, out, n, row, first,
+                           nb, sm1, tie_mode);
     return check_launch();
 }
 
 int qd_clamp_f32(float* w, int64_t n, float limit, void* stream) {
     if (n < 0 || (n > 0 && !w)) return QD_ERR_INVALID_ARGUMENT;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_clamp, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, w, n, limit);
+    hipLaunchKernelGGL(k_clamp, dim3(blocks_for(n, 256 * 4 * 4)), dim3(256), 0, (hipStream_t)stream, w, n, limit);
     return check_launch();
 }
 
 int qd_truncated_ste_f32(const float* w, float* grad, int64_t n, float limit, void* stream) {
     if (n < 0 || (n > 0 && (!w || !grad))) return QD_ERR_INVALID_ARGUMENT;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_truncated_ste, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, w, grad, n,
+    hipLaunchKernelGGL(k_truncated_ste, dim3(blocks_for(n, 256 * 4 * 4)), dim3(256), 0, (hipStream_t)stream, w, grad, n,
                        limit);
     return check_launch();
 }

@@ -1,10 +1,13 @@
-"""Drop-in for the reference's `quantization` package (quantization/__init__.py:1-8)."""
-import torch
+"""Drop-in for the reference's `quantization` package: same exported names
+(ref: quantization/__init__.py:1-8), implemented on libqd_hip.so."""
+import torch as _torch
 
-USE_CUDA = torch.cuda.is_available()
-from .quant_functions import (ScalingFunction, nonUniformQuantization, nonUniformQuantization_variable,  # noqa: E402
-                              uniformQuantization, uniformQuantization_variable)
-from . import help_functions, quant_functions  # noqa: E402,F401
+from . import help_functions, quant_functions  # noqa: F401
+
+USE_CUDA = _torch.cuda.is_available()          # read by callers, ref: quant_functions.py:484
 
 __all__ = ('uniformQuantization', 'ScalingFunction', 'nonUniformQuantization',
            'uniformQuantization_variable', 'nonUniformQuantization_variable')
+for _name in __all__:
+    globals()[_name] = getattr(quant_functions, _name)
+del _name
