@@ -77,7 +77,7 @@ def cpu_baseline(x_host):
         'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(),
     }
     # the reference's own op chain (multi-threaded torch CPU ops), restated in oracle/torch_port.py
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))     # 256 SMT threads oversubscribe torch's elementwise ops
     uniform_quantize_torch_ops(x_host, LEVELS, BUCKET)
     tt = []
     t_end = time.time() + 12.0
@@ -91,7 +91,51 @@ def cpu_baseline(x_host):
         'sample': '%d runs, min %.4f s, median %.4f s; same sequence of torch CPU ops as '
                   'quantization/quant_functions.py:155-194' % (len(tt), min(tt), float(np.median(tt))),
     }
+    out['distill'] = cpu_distill_baseline()
     return out
+
+
+def cpu_distill_baseline(steps=12, warmup=2, batch=50):
+    """BASELINE configs[0]: the CIFAR10 ConvolForwardNet student step on the CPU with the
+    reference's quantizer (its torch-op chain, oracle/torch_port.py) in the reference's loop shape
+    (quantize every parameter, fwd/bwd with the KD loss, restore, SGD) -- bounded sample."""
+    from harness import models
+    from oracle.torch_port import uniform_quantize_torch_ops
+    torch.manual_seed(0)
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    st, te = models.student().train(), models.teacher().eval()
+    opt = torch.optim.SGD(st.parameters(), lr=1e-3, momentum=0.9, nesterov=True, weight_decay=2.2e-4)
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(batch, 3, 32, 32, generator=g), torch.randint(0, 10, (batch,), generator=g)
+    t_quant = 0.0
+
+    def one():
+        nonlocal t_quant
+        a = time.perf_counter()
+        saved = [p.data for p in st.parameters()]
+        for p in st.parameters():
+            p.data = uniform_quantize_torch_ops(p.data, 16, 256)[0]
+        t_quant += time.perf_counter() - a
+        opt.zero_grad()
+        with torch.no_grad():
+            t_out = te(x)
+        models.kd_loss(st(x), t_out, y).backward()
+        for p, m in zip(st.parameters(), saved):
+            p.data = m
+        opt.step()
+
+    for _ in range(warmup):
+        one()
+    t_quant = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2),
+            'quantize_ms_per_step': round(t_quant / steps * 1e3, 3), 'threads': threads,
+            'sample': '%d steps, batch %d, synthetic CIFAR10-shaped data; student+teacher fwd, KD loss, bwd, SGD on the '
+                      'host with the torch-op port of the reference quantizer (configs[0])' % (steps, batch)}
 
 
 def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, per_gpu_batch=50):
@@ -106,7 +150,7 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
     out = {'config': 'CIFAR10-shaped synthetic randn(B,3,32,32), ConvolForwardNet student (22 tensors, 1.00 M '
                      'params) distilled from the 5.3 M teacher, KD loss T=2, SGD nesterov, 4-bit uniform, bucket 256, STE',
            'per_gpu_batch': per_gpu_batch, 'global_batch': per_gpu_batch * n_gpus, 'steps': steps, 'warmup': warmup}
-    for mode in ('multi_graph', 'multi', 'per_tensor'):
+    for mode in ('multi', 'per_tensor'):
         tr = DistillTrainer(models.student(), models.teacher(), dev, num_bits=4, bucket_size=256,
                             mode='multi' if mode == 'multi_graph' else mode)
         batches = [synthetic_batch(per_gpu_batch, dev, seed=1000 * rank + i) for i in range(4)]
@@ -153,9 +197,10 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
         out[mode] = {'steps_per_sec': round(steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
                      'samples_per_sec': round(steps * per_gpu_batch * n_gpus / dt, 1), 'phases': phases}
         del tr
-    out['note'] = ("'multi' = one multi-tensor quantize launch per step on persistent shadows (K9); 'multi_graph' = the "
-                   "same step replayed from two hipGraphs (quantize+fwd+bwd | SGD) with the all-reduce between them; "
-                   "'per_tensor' = the reference's loop shape (22 uniformQuantization calls + restore)")
+    out['note'] = ("'multi' = one multi-tensor quantize launch per step on persistent shadows (K9); 'per_tensor' = the "
+                   "reference's loop shape (22 uniformQuantization calls + restore).  hipGraph replay of the step "
+                   "(DistillTrainer.capture) measured no gain: the step is bound by MIOpen's small-shape conv kernels, "
+                   "not by launches (profiles/r01_distill_notes.txt)")
     return out
 
 
@@ -183,7 +228,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
+    # QD_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-reduce) even with a single rank
+    distributed = world > 1 or os.environ.get('QD_FORCE_DIST') == '1'
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)

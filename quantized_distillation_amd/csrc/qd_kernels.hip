@@ -611,118 +611,142 @@ __global__ __launch_bounds__(256) void k_arg_final(const float* pv, const int64_
 }
 
 // ---- K6: point gradient (quant_functions.py:493-503) ------------------------------------------
-// stage 1: every block accumulates sum_{idx==j} g*alpha over its slice into k bins.
-// KR > 0: bins live in registers (k <= KR, fully unrolled select-accumulate, deterministic);
-// KR == 0: bins live in LDS, one private set per wave (k <= kMaxPoints).
-// 16-byte g loads + packed 4-byte (uint8 x4) or 2 x 16-byte (int64 x4) index loads; the bucket of
-// an element is a shift when the bucket size is a power of two (no integer division per element).
+//     grad_points[j] = sum_{i: idx_i == j} g_i * alpha_bucket(i)
+// stage 1 (fast path): 16-byte g loads + packed 4-byte (uint8 x4) or 2 x 16-byte (int64 x4) index
+// loads, two float4 in flight per lane, bucket = element >> shift (power-of-two buckets) or 0.
+//   KR > 0 : k <= KR bins in registers, unrolled select-accumulate (k <= 4);
+//   KR == 0: bins[k][256] in LDS, every lane owns a private column and does a plain
+//            read-add-write (no atomics: LDS float atomics retire ~1 lane per 3 cycles on gfx950,
+//            measured 390 us for the 64 Mi-element tensor); k <= 64.
+// Both are deterministic: fixed per-lane order, fixed fold order.
 template <int KR>
-struct PgAcc {
+struct PgBins {
     float acc[KR > 0 ? KR : 1];
-    float* lds;
-    __device__ __forceinline__ void init(float* wave_bins) {
-        lds = wave_bins;
+    float* col;
+    __device__ __forceinline__ void init(float* lds_col) {
+        col = lds_col;
 #pragma unroll
         for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] = 0.0f;
     }
     __device__ __forceinline__ void add(int id, float m) {
         if (KR > 0) {
 #pragma unroll
-            for (int j = 0; j < KR; ++j) acc[j] += (id == j) ? m : 0.0f;
+            for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] += (id == j) ? m : 0.0f;
         } else {
-            atomicAdd(&lds[id], m);                       // LDS atomic on wave-private bins
+            col[id * 256] += m;                             // private column: plain LDS read-add-write
         }
     }
 };
 
-template <int KR>
-__global__ __launch_bounds__(256) void k_point_grad_partial(const float* g, const void* idx, int idx_bytes,
-                                                            const float* alpha, int64_t n, int64_t row, int64_t nb,
-                                                            int row_shift, int k, float* part /* [grid][k] */) {
-    __shared__ float bins[KR > 0 ? 4 * 16 : 4 * kMaxPoints];
+template <int KR, int IDXB, bool BUCKETED>
+__global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const void* idx, const float* alpha, int64_t n,
+                                                         int row_shift, int k, float* part /* [grid][k] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // KR == 0: [k][256]; KR > 0: [4][KR]
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int stride = KR > 0 ? 16 : kMaxPoints;
     if (KR == 0) {
-        for (int j = lane; j < k; j += 64) bins[w * stride + j] = 0.0f;
+        for (int j = threadIdx.x; j < k * 256; j += 256) lds[j] = 0.0f;
         __syncthreads();
     }
-    PgAcc<KR> A;
-    A.init(bins + w * stride);
-    const bool small = n < (int64_t)0xFFFFFFFFll;
-    auto bucket_of = [&](int64_t e) -> int64_t {
-        if (nb == 1) return 0;
-        if (row_shift >= 0) return e >> row_shift;
-        return small ? (int64_t)((uint32_t)e / (uint32_t)row) : e / row;
+    PgBins<KR> B;
+    B.init(lds + threadIdx.x);
+    const float a_single = BUCKETED ? 0.0f : alpha[0];
+    const int64_t n4 = n >> 2;
+    auto load4 = [&](int64_t i, f4& gv, int (&id)[4], float& a) {
+        gv = __builtin_nontemporal_load((const f4*)g + i);
+        if (IDXB == 8) {
+            const l2 p0 = __builtin_nontemporal_load((const l2*)idx + 2 * i);
+            const l2 p1 = __builtin_nontemporal_load((const l2*)idx + 2 * i + 1);
+            id[0] = (int)p0.x; id[1] = (int)p0.y; id[2] = (int)p1.x; id[3] = (int)p1.y;
+        } else {
+            const uint32_t pk = __builtin_nontemporal_load((const uint32_t*)idx + i);
+            id[0] = pk & 255; id[1] = (pk >> 8) & 255; id[2] = (pk >> 16) & 255; id[3] = pk >> 24;
+        }
+        a = BUCKETED ? alpha[(i << 2) >> row_shift] : a_single;
     };
-    const bool idx_ok = idx_bytes == 8 ? ((((uintptr_t)idx) & 15) == 0) : ((((uintptr_t)idx) & 3) == 0);
-    const bool vec = ((((uintptr_t)g) & 15) == 0) && idx_ok && (nb == 1 || (row & 3) == 0);
-    int64_t done = 0;
-    if (vec) {
-        const int64_t n4 = n >> 2;
-        auto load_idx = [&](int64_t i, int& i0, int& i1, int& i2, int& i3) {
-            if (idx_bytes == 8) {
-                const l2 p0 = __builtin_nontemporal_load((const l2*)idx + 2 * i);
-                const l2 p1 = __builtin_nontemporal_load((const l2*)idx + 2 * i + 1);
-                i0 = (int)p0.x; i1 = (int)p0.y; i2 = (int)p1.x; i3 = (int)p1.y;
-            } else {
-                const uint32_t pk = __builtin_nontemporal_load((const uint32_t*)idx + i);
-                i0 = pk & 255; i1 = (pk >> 8) & 255; i2 = (pk >> 16) & 255; i3 = pk >> 24;
-            }
-        };
-        int64_t i = tid;
-        for (; i + nth < n4; i += 2 * nth) {              // two independent float4 in flight per lane
-            const int64_t i2 = i + nth;
-            const f4 ga = __builtin_nontemporal_load((const f4*)g + i);
-            const f4 gb = __builtin_nontemporal_load((const f4*)g + i2);
-            int a0, a1, a2, a3, b0, b1, b2, b3;
-            load_idx(i, a0, a1, a2, a3);
-            load_idx(i2, b0, b1, b2, b3);
-            const float sa = alpha[bucket_of(i << 2)], sb = alpha[bucket_of(i2 << 2)];
-            A.add(a0, ga.x * sa); A.add(a1, ga.y * sa); A.add(a2, ga.z * sa); A.add(a3, ga.w * sa);   // one fp32 multiply each, :495
-            A.add(b0, gb.x * sb); A.add(b1, gb.y * sb); A.add(b2, gb.z * sb); A.add(b3, gb.w * sb);
-        }
-        for (; i < n4; i += nth) {
-            const f4 ga = __builtin_nontemporal_load((const f4*)g + i);
-            int a0, a1, a2, a3;
-            load_idx(i, a0, a1, a2, a3);
-            const float sa = alpha[bucket_of(i << 2)];
-            A.add(a0, ga.x * sa); A.add(a1, ga.y * sa); A.add(a2, ga.z * sa); A.add(a3, ga.w * sa);
-        }
-        done = n4 << 2;
+    auto accumulate = [&](const f4& gv, const int (&id)[4], float a) {
+        B.add(id[0], gv.x * a);                              // one fp32 multiply each, :495
+        B.add(id[1], gv.y * a);
+        B.add(id[2], gv.z * a);
+        B.add(id[3], gv.w * a);
+    };
+    int64_t i = tid;
+    for (; i + nth < n4; i += 2 * nth) {                     // two independent float4 in flight per lane
+        f4 ga, gb; int ia[4], ib[4]; float sa, sb;
+        load4(i, ga, ia, sa);
+        load4(i + nth, gb, ib, sb);
+        accumulate(ga, ia, sa);
+        accumulate(gb, ib, sb);
     }
-    for (int64_t i = done + tid; i < n; i += nth) {
-        const float m = g[i] * alpha[bucket_of(i)];
-        const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
-        A.add(id, m);
+    if (i < n4) {
+        f4 ga; int ia[4]; float sa;
+        load4(i, ga, ia, sa);
+        accumulate(ga, ia, sa);
+    }
+    for (int64_t e = (n4 << 2) + tid; e < n; e += nth) {     // n % 4 leftover elements
+        const int id = IDXB == 8 ? (int)((const int64_t*)idx)[e] : (int)((const uint8_t*)idx)[e];
+        B.add(id, g[e] * (BUCKETED ? alpha[e >> row_shift] : a_single));
     }
     if (KR > 0) {
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
         for (int j = 0; j < (KR > 0 ? KR : 1); ++j) {
-            const float sum = wave_sum(A.acc[j]);
-            if (lane == 0) bins[w * stride + j] = sum;
+            const float sum = wave_sum(B.acc[j]);
+            if (lane == 0) lds[w * KR + j] = sum;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < k; j += 256)
+            part[(int64_t)blockIdx.x * k + j] = (lds[j] + lds[KR + j]) + (lds[2 * KR + j] + lds[3 * KR + j]);
+    } else {
+        __syncthreads();
+        // 4 threads per bin, 64 columns each, rotated start (bank-conflict free), then a fixed fold
+        for (int t = threadIdx.x; t < k * 4; t += 256) {
+            const int j = t >> 2, q = t & 3;
+            float acc = 0.0f;
+            for (int c = 0; c < 64; ++c) acc += lds[j * 256 + q * 64 + ((c + j) & 63)];
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (q == 0) part[(int64_t)blockIdx.x * k + j] = acc;
         }
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < k; j += blockDim.x)
-        part[(int64_t)blockIdx.x * k + j] =
-            (bins[j] + bins[stride + j]) + (bins[2 * stride + j] + bins[3 * stride + j]);
 }
-// stage 2: fold of the per-block partials in a fixed order (thread t sums rows t, t+256, ... in
-// float64, then a fixed shuffle/LDS tree), so the result is reproducible run to run
+
+// stage 1 (generic path): any alignment / bucket size / k <= 1024; LDS table bins[k][C] with
+// atomics (lanes that share a column and an index collide; correct, order of those not fixed).
+__global__ __launch_bounds__(256) void k_point_grad_generic(const float* g, const void* idx, int idx_bytes,
+                                                            const float* alpha, int64_t n, int64_t row, int64_t nb,
+                                                            int k, int C, float* part /* [grid][k] */) {
+    extern __shared__ __attribute__((aligned(16))) float bins[];        // [k][C]
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    for (int j = threadIdx.x; j < k * C; j += blockDim.x) bins[j] = 0.0f;
+    __syncthreads();
+    float* col = bins + (threadIdx.x % C);
+    const bool small = n < (int64_t)0xFFFFFFFFll;
+    for (int64_t i = tid; i < n; i += nth) {
+        const int64_t bkt = nb == 1 ? 0 : (small ? (int64_t)((uint32_t)i / (uint32_t)row) : i / row);
+        const float m = g[i] * alpha[bkt];
+        const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
+        atomicAdd(col + id * C, m);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) acc += bins[j * C + ((c + j) % C)];
+        part[(int64_t)blockIdx.x * k + j] = acc;
+    }
+}
+// stage 2: one block per bin folds the per-block partials in a fixed order (thread t sums rows
+// t, t+256, ... in float64, then a fixed shuffle/LDS tree): reproducible run to run
 __global__ __launch_bounds__(256) void k_point_grad_final(const float* part, int nblocks, int k, float* out) {
     __shared__ double red[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int j = 0; j < k; ++j) {
-        double acc = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += 256) acc += (double)part[(int64_t)b * k + j];
-        acc = wave_sum_d(acc);
-        __syncthreads();
-        if (lane == 0) red[w] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) out[j] = (float)((red[0] + red[1]) + (red[2] + red[3]));
-    }
+    const int j = blockIdx.x;
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += (double)part[(int64_t)b * k + j];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[j] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // ---- K7 (vector path): the whole bucket lives in registers (x, g, q as float4), one pass ------
@@ -1237,21 +1261,34 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     int64_t nb, row;
     geometry(n > 0 ? n : 1, bucket, nb, row);
     // partial rows of k floats each must fit the workspace's [kPartialBlocks * kMaxPoints] floats
-    int blocks = blocks_for(n, 256 * 4 * 4);
+    int blocks = blocks_for(n, 256 * 4 * 2);
     const int64_t max_rows = (int64_t)kPartialBlocks * kMaxPoints / k;
-    const int64_t cap = k <= 16 ? 8192 : 2048;
+    const int64_t cap = k <= 64 ? 8192 : 2048;
     if (blocks > cap) blocks = (int)cap;
     if (blocks > max_rows) blocks = (int)max_rows;
-    int row_shift = -1;
-    if (nb > 1 && (row & (row - 1)) == 0) { row_shift = 0; while (((int64_t)1 << row_shift) < row) ++row_shift; }
-#define QD_PG(KR) hipLaunchKernelGGL((k_point_grad_partial<KR>), dim3(blocks), dim3(256), 0, st, g, idx, idx_bytes, \
-                                     alpha, n, row, nb, row_shift, k, w.pg_part)
-    if (k <= 4) QD_PG(4);
-    else if (k <= 8) QD_PG(8);
-    else if (k <= 16) QD_PG(16);
-    else QD_PG(0);
+    int row_shift = 0;
+    const bool pow2 = nb == 1 || (row & (row - 1)) == 0;
+    if (nb > 1 && pow2) while (((int64_t)1 << row_shift) < row) ++row_shift;
+    const bool idx_ok = idx_bytes == 8 ? ((((uintptr_t)idx) & 15) == 0) : ((((uintptr_t)idx) & 3) == 0);
+    const bool fast = k <= 64 && pow2 && idx_ok && ((((uintptr_t)g) & 15) == 0) && (nb == 1 || row >= 4);
+    if (fast) {
+#define QD_PG(KR, IDXB, BK)                                                                                         \
+        hipLaunchKernelGGL((k_point_grad_fast<KR, IDXB, BK>), dim3(blocks), dim3(256),                              \
+                           (size_t)(KR > 0 ? 4 * KR : k * 256) * sizeof(float), st, g, idx, alpha, n, row_shift, k, \
+                           w.pg_part)
+#define QD_PG_K(IDXB, BK) { if (k <= 4) QD_PG(4, IDXB, BK); else QD_PG(0, IDXB, BK); }
+        if (idx_bytes == 8) { if (nb > 1) QD_PG_K(8, true) else QD_PG_K(8, false) }
+        else { if (nb > 1) QD_PG_K(1, true) else QD_PG_K(1, false) }
+#undef QD_PG_K
 #undef QD_PG
-    hipLaunchKernelGGL(k_point_grad_final, dim3(1), dim3(256), 0, st, w.pg_part, blocks, k, grad_points);
+    } else {
+        int C = 256;                                     // columns of the LDS table, k*C*4 bytes <= 64 KiB
+        while ((int64_t)k * C > 16384 && C > 16) C >>= 1;
+        if (k > 16 && C > 64) C = 64;
+        hipLaunchKernelGGL(k_point_grad_generic, dim3(blocks), dim3(256), (size_t)k * C * sizeof(float), st, g, idx,
+                           idx_bytes, alpha, n, row, nb, k, C, w.pg_part);
+    }
+    hipLaunchKernelGGL(k_point_grad_final, dim3(k), dim3(256), 0, st, w.pg_part, blocks, k, grad_points);
     return check_launch();
 }
 

@@ -76,6 +76,48 @@ __global__ void k_qdq(const float* x, float* q, int64_t nb, float sm1) {
     }
 }
 
+
+// ---- K6 probes: what bounds the point-gradient stage-1 kernel?  LEVEL 0: read g only (sum);
+// 1: + packed uint8 index loads; 2: + alpha[bucket] loads; 3: + k=4 select-accumulate (the real thing)
+template <int LEVEL, int UNR>
+__global__ __launch_bounds__(256) void k_pg_probe(const float* g, const uint8_t* idx, const float* alpha, int64_t n,
+                                                  float* part) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n >> 2;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i0 = tid; i0 < n4; i0 += UNR * nth) {
+        f4 gv[UNR]; uint32_t pk[UNR]; float al[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + u * nth;
+            if (i < n4) {
+                gv[u] = __builtin_nontemporal_load((const f4*)g + i);
+                pk[u] = LEVEL >= 1 ? __builtin_nontemporal_load((const uint32_t*)idx + i) : 0u;
+                al[u] = LEVEL >= 2 ? alpha[(i << 2) >> 8] : 1.0f;
+            } else { gv[u] = f4{0.f, 0.f, 0.f, 0.f}; pk[u] = 0; al[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (LEVEL <= 2) {
+                acc[0] += gv[u].x * al[u]; acc[1] += gv[u].y * al[u]; acc[2] += gv[u].z * al[u]; acc[3] += gv[u].w * al[u];
+                acc[0] += (float)(pk[u] & 1);
+            } else {
+                const int i0_ = pk[u] & 255, i1_ = (pk[u] >> 8) & 255, i2_ = (pk[u] >> 16) & 255, i3_ = pk[u] >> 24;
+                const float m0 = gv[u].x * al[u], m1 = gv[u].y * al[u], m2 = gv[u].z * al[u], m3 = gv[u].w * al[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] += (i0_ == j) ? m0 : 0.f; acc[j] += (i1_ == j) ? m1 : 0.f;
+                    acc[j] += (i2_ == j) ? m2 : 0.f; acc[j] += (i3_ == j) ? m3 : 0.f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < 4; ++j) part[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + j] = acc[j];
+}
 struct Variant { std::string name; std::function<void(int)> run; std::vector<float> us; };
 
 int main(int argc, char** argv) {
@@ -107,6 +149,13 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(x[i], h.data(), N * 4, hipMemcpyHostToDevice));
     }
     hipStream_t st0; CK(hipStreamCreate(&st0));
+    uint8_t* idx8[4]; float* alph; float* part;
+    {
+        std::vector<uint8_t> hi(N);
+        for (int64_t i = 0; i < N; ++i) hi[i] = (uint8_t)((i * 2654435761u >> 13) & 3);
+        for (int i = 0; i < 4; ++i) { CK(hipMalloc(&idx8[i], N)); CK(hipMemcpy(idx8[i], hi.data(), N, hipMemcpyHostToDevice)); }
+        CK(hipMalloc(&alph, nb * 4)); CK(hipMemset(alph, 0, nb * 4)); CK(hipMalloc(&part, 65536 * 16 * 4));
+    }
     std::vector<Variant> vs;
     auto addq = [&](const char* nm, auto kern, int block, int64_t tiles_per_wave_iter, int64_t cap) {
         vs.push_back({nm, [=](int i) {
@@ -120,6 +169,26 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st0, (const f4*)x[i & 3], (f4*)y[i & 3], N / 4);
         }, {}});
     };
+    auto addp = [&](const char* nm, auto kern, int blocks) {
+        vs.push_back({nm, [=](int i) {
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st0, (const float*)x[i & 3], (const uint8_t*)idx8[i & 3], (const float*)alph, N, part);
+        }, {}});
+    };
+    if (argc > 3 && std::string(argv[3]) == "pg") {
+        addp("pg L0 read g only, unr1, 8192 blk", k_pg_probe<0, 1>, 8192);
+        addp("pg L0 read g only, unr2, 8192 blk", k_pg_probe<0, 2>, 8192);
+        addp("pg L0 read g only, unr4, 8192 blk", k_pg_probe<0, 4>, 8192);
+        addp("pg L0 read g only, unr4, 16384 blk", k_pg_probe<0, 4>, 16384);
+        addp("pg L0 read g only, unr1, 65536 blk", k_pg_probe<0, 1>, 65536);
+        addp("pg L0 read g only, unr4, 2048 blk", k_pg_probe<0, 4>, 2048);
+        addp("pg L1 + u8 idx, unr2, 8192", k_pg_probe<1, 2>, 8192);
+        addp("pg L1 + u8 idx, unr4, 8192", k_pg_probe<1, 4>, 8192);
+        addp("pg L2 + alpha, unr2, 8192", k_pg_probe<2, 2>, 8192);
+        addp("pg L2 + alpha, unr4, 8192", k_pg_probe<2, 4>, 8192);
+        addp("pg L3 + k=4 bins, unr2, 8192", k_pg_probe<3, 2>, 8192);
+        addp("pg L3 + k=4 bins, unr4, 8192", k_pg_probe<3, 4>, 8192);
+        addp("pg L3 + k=4 bins, unr4, 16384", k_pg_probe<3, 4>, 16384);
+    } else {
     addc("copy nt V4 full", k_copy<true, 4>, 4, 0);
     addc("copy plain V4 full", k_copy<false, 4>, 4, 0);
     addc("copy nt V1 full", k_copy<true, 1>, 1, 0);
@@ -135,6 +204,7 @@ int main(int argc, char** argv) {
     addq("qdq nt L16V4 b256 cap8192", k_qdq<true, 16, 4, 0>, 256, nb / 4, 8192);
     addq("qdq nt L16V4 b256 cap2048", k_qdq<true, 16, 4, 0>, 256, nb / 4, 2048);
     addq("qdq nt L16V4 b256 rcp(not exact)", k_qdq<true, 16, 4, 1>, 256, nb / 4, 0);
+    }
     // sustained mode: the chip's power management cuts clocks after a few ms of continuous
     // streaming; report 100-launch chunks of an uninterrupted 800-launch run per variant
     if (argc > 1 && std::string(argv[1]) == "sustained") {
