@@ -204,6 +204,50 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
     return out
 
 
+def diffquant_steps_per_sec(dev, steps=8, warmup=2, batch=100):
+    """BASELINE configs[2]: CIFAR10 WideResNet-16-22 student (60 tensors, 82.7 M parameters), 2-bit
+    (k = 4 points) non-uniform differentiable quantization, bucket 256, 1 GPU: steps/sec of the
+    optimize_quantization_points loop with the per-step quantizer cost broken out."""
+    from harness import models
+    from harness.diffquant import DiffQuantTrainer
+    from harness.distill import synthetic_batch
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    tr = DiffQuantTrainer(models.WideResNet(16, 22), dev, num_points=4, bucket_size=256, lr=1e-5)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    x, y = synthetic_batch(batch, dev, seed=11)
+    for _ in range(warmup):
+        tr.step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(x, y)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    phases = {}
+
+    def timed(name, fn, reps=5):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        phases[name] = round((time.perf_counter() - a) / reps * 1e3, 3)
+    timed('assign_all_tensors_ms (K5 x60)', tr.quantize)
+    timed('fwd_bwd_ms', lambda: tr.forward_backward(x, y))
+    timed('point_gradients_ms (K6 x60)', tr.point_gradients)
+    nparams = sum(p.numel() for p in tr.params)
+    return {'config': 'Wide_ResNet depth 16 widen 22 (60 tensors, %.1f M params), k=4 points (2-bit) per tensor, bucket 256, '
+                      'percentile init, KD loss vs the unquantized model, SGD on the points; batch %d synthetic CIFAR10-shaped'
+                      % (nparams / 1e6, batch),
+            'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2), 'steps': steps,
+            'setup_s': round(setup_s, 2), 'phases': phases,
+            'reference_cpu_quantizer_note': 'reference per-step quantizer cost on this model, CPU path: ~2.5 s per 16 Mi-element '
+                                            'tensor (BASELINE.md section 3); here the 60-tensor assign + point-gradient pair is the '
+                                            'two phase entries above'}
+
+
 def load_pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), if present."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -222,6 +266,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-distill', action='store_true', help='skip the distilled-training steps/sec leg')
+    ap.add_argument('--no-diffquant', action='store_true', help='skip the WideResNet differentiable-quantization leg')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
     args = ap.parse_args()
 
@@ -323,6 +368,9 @@ def main():
         del live[:], xs[1:]
         torch.cuda.empty_cache()
         distill = distill_steps_per_sec(dev, rank, n_gpus, distributed)
+        if n_gpus == 1 and not args.no_diffquant:
+            torch.cuda.empty_cache()
+            distill['diffquant_wrn'] = diffquant_steps_per_sec(dev)
 
     if rank == 0:
         bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM

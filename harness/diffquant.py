@@ -1,0 +1,85 @@
+"""One step of differentiable quantization, MI355X-native.
+
+Restates the reference's loop (ref: cnn_models/conv_forward_model.py:395-592): the weights are
+frozen, the k quantization points of every tensor are trained by SGD; each step re-assigns every
+weight to its nearest point (K5), runs student (quantized copy) and teacher (the original model)
+forward, the KD loss, backward, and reduces the weight gradient to the k point gradients (K6).
+
+    reference, per tensor per step                        here
+    ----------------------------------------------------  ---------------------------------------
+    points -> numpy; SearchSorted.query on the CPU;        one kernel: u (resident, fp32) -> q + uint8
+    build int64 index + fp32 value arrays; H2D of both     index; nothing leaves the device
+    k masked_select(...).sum() passes (+ k host syncs)     one two-stage segmented reduction
+
+In data-parallel runs only the point gradients are exchanged (ntensors x k floats, ~1 KB for
+WRN-16-22) instead of the 331 MB weight gradient.
+"""
+import copy
+
+import torch
+import torch.distributed as dist
+
+import quantization
+import quantization.help_functions as qhf
+
+from . import models
+
+
+class DiffQuantTrainer(object):
+    def __init__(self, model, device, num_points=4, bucket_size=256, lr=1e-5, momentum=0.9, nesterov=True,
+                 quantize_first_and_last_layer=True):
+        self.device = device
+        self.teacher = model.to(device).eval()                       # ref: :496 modelToQuantize.eval()
+        for p in self.teacher.parameters():
+            p.requires_grad_(False)
+        self.student = copy.deepcopy(self.teacher).train()           # ref: :498,:516
+        for p in self.student.parameters():
+            p.requires_grad_(True)
+        params = list(self.student.parameters())
+        n = len(params)
+        self.slots = [i for i in range(n) if quantize_first_and_last_layer or (i != 0 and i != n - 1)]
+        self.params = params
+        self.k = num_points
+        scaling = quantization.ScalingFunction('linear', False, False, bucket_size, False)     # ref: :421
+        # all points live in ONE [ntensors, k] tensor: one optimizer state, one all-reduce
+        self.points = torch.empty(len(self.slots), num_points, device=device)
+        self.points_grad = torch.zeros_like(self.points)
+        self.fns = []
+        for row, i in enumerate(self.slots):
+            w = params[i].data
+            self.points[row] = qhf.initialize_quantization_points(w, scaling, num_points)      # ref: :460-462
+            self.fns.append(quantization.nonUniformQuantization_variable(
+                bucket_size=bucket_size, pre_process_tensors=True, tensor=w))                  # ref: :507-509
+        self.points.grad = self.points_grad
+        opts = dict(momentum=momentum, nesterov=nesterov) if momentum != 0 else {}
+        self.opt = torch.optim.SGD([self.points], lr=lr, **opts)                                # ref: :482-484
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def quantize(self):
+        for row, i in enumerate(self.slots):                                                    # ref: :524-532
+            self.params[i].data = self.fns[row].forward(None, self.points[row])
+
+    def forward_backward(self, images, labels):
+        for p in self.params:
+            p.grad = None
+        out = self.student(images)
+        with torch.no_grad():
+            t_out = self.teacher(images)
+        loss = models.kd_loss(out, t_out, labels)                                               # ref: :534-536
+        loss.backward()
+        return loss
+
+    def point_gradients(self):
+        for row, i in enumerate(self.slots):                                                    # ref: :538-545
+            self.points_grad[row] = self.fns[row].backward(self.params[i].grad)[1]
+
+    def step(self, images, labels):
+        self.quantize()
+        loss = self.forward_backward(images, labels)
+        self.point_gradients()
+        if self.world > 1:                               # exchange only ntensors*k floats
+            dist.all_reduce(self.points_grad)
+            self.points_grad.mul_(1.0 / self.world)
+        self.opt.step()
+        self.points.copy_(torch.sort(self.points, dim=1)[0])                                    # ref: :550-551
+        return loss

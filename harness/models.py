@@ -60,3 +60,53 @@ def kd_loss(student_logits, teacher_logits, labels, temperature=2.0, teacher_wei
     kl = F.kl_div(F.log_softmax(student_logits / temperature, dim=1),
                   F.softmax(teacher_logits / temperature, dim=1), reduction='sum') / student_logits.numel()
     return teacher_weight * temperature ** 2 * kl + (1.0 - teacher_weight) * F.cross_entropy(student_logits, labels)
+
+
+# ---------------------------------------------------------------------------------------------
+class _WideBlock(nn.Module):
+    """Pre-activation wide residual block (BN-ReLU-conv3x3, BN-ReLU-conv3x3 [stride], 1x1
+    shortcut when the shape changes), biases on, as in the reference's wide_basic
+    (ref: cnn_models/wide_resnet.py:27-48).  Dropout is a no-op at rate 0 and omitted."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(cin)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, bias=True)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, stride=stride, padding=1, bias=True)
+        self.shortcut = nn.Conv2d(cin, cout, 1, stride=stride, bias=True) if (stride != 1 or cin != cout) else None
+
+    def forward(self, x):
+        out = self.conv1(F.relu(self.bn1(x)))
+        out = self.conv2(F.relu(self.bn2(out)))
+        return out + (x if self.shortcut is None else self.shortcut(x))
+
+
+class WideResNet(nn.Module):
+    """Wide_ResNet(depth, widen) for 32x32 inputs (ref: cnn_models/wide_resnet.py:50-88):
+    conv3x3(3,16), three stages of (depth-4)/6 blocks at widths 16k, 32k, 64k, BN, 8x8 average
+    pool, linear.  depth 16 / widen 22 is config 3's student: 60 tensors, 82.7 M parameters."""
+
+    def __init__(self, depth=16, widen=22, classes=10):
+        super().__init__()
+        assert (depth - 4) % 6 == 0
+        n = (depth - 4) // 6
+        widths = [16, 16 * widen, 32 * widen, 64 * widen]
+        self.conv1 = nn.Conv2d(3, widths[0], 3, padding=1, bias=True)
+        blocks, cin = [], widths[0]
+        for stage, stride in ((1, 1), (2, 2), (3, 2)):
+            for b in range(n):
+                blocks.append(_WideBlock(cin, widths[stage], stride if b == 0 else 1))
+                cin = widths[stage]
+        self.blocks = nn.Sequential(*blocks)
+        self.bn1 = nn.BatchNorm2d(widths[3], momentum=0.9)
+        self.linear = nn.Linear(widths[3], classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight, gain=2 ** 0.5)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        out = self.blocks(self.conv1(x))
+        out = F.avg_pool2d(F.relu(self.bn1(out)), 8)
+        return self.linear(out.flatten(1))

@@ -77,3 +77,38 @@ def test_graph_replay_matches_eager():
         la, lb = a.step(x, y), b.step(x, y)
         assert abs(float(la) - float(lb)) <= 1e-4 * max(1.0, abs(float(la)))
     assert torch.allclose(a.flat_master, b.flat_master, rtol=1e-3, atol=1e-5)
+
+
+def test_diffquant_step_against_oracle():
+    """One differentiable-quantization step: quantized weights, indices and point gradients of
+    every tensor equal the oracle's; the points move and stay sorted."""
+    from harness.diffquant import DiffQuantTrainer
+    torch.manual_seed(0)
+    net = models.student()
+    tr = DiffQuantTrainer(net, DEV, num_points=4, bucket_size=256, lr=1e-2)
+    masters = [p.detach().cpu().numpy().copy() for p in tr.teacher.parameters()]
+    pts0 = tr.points.clone()
+    for row, i in enumerate(tr.slots):
+        want = onp.init_points_percentile(masters[i], 256, 4)
+        assert np.array_equal(pts0[row].cpu().numpy(), want), i
+    x, y = synthetic_batch(16, DEV, seed=3)
+    tr.quantize()
+    for row, i in enumerate(tr.slots):
+        r = onp.nonuniform_quantize(masters[i], pts0[row].cpu().numpy(), 256, mode='midpoint')
+        assert np.array_equal(tr.params[i].detach().cpu().numpy(), r['q']), i
+    tr.forward_backward(x, y)
+    tr.point_gradients()
+    for row, i in enumerate(tr.slots):
+        r = onp.nonuniform_quantize(masters[i], pts0[row].cpu().numpy(), 256, mode='midpoint')
+        g = tr.params[i].grad.cpu().numpy()
+        want, absum = onp.point_grad(g, r['idx'], r['alpha'], 256, 4)
+        got = tr.points_grad[row].cpu().numpy().astype(np.float64)
+        assert np.all(np.abs(got - want) <= 4e-6 * absum + 1e-30), (i, got, want)
+    tr.opt.step()
+    tr.points.copy_(torch.sort(tr.points, dim=1)[0])
+    assert not torch.equal(tr.points, pts0)
+    assert bool((tr.points[:, 1:] >= tr.points[:, :-1]).all())
+    # teacher (the original weights) is untouched
+    for p, m in zip(tr.teacher.parameters(), masters):
+        assert np.array_equal(p.detach().cpu().numpy(), m)
+    assert torch.isfinite(tr.step(x, y))
