@@ -204,6 +204,73 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
     return out
 
 
+def dp_config_steps_per_sec(kind, dev, rank, n_gpus, distributed, steps=10, warmup=3):
+    """BASELINE configs[3] (kind='imagenet': ImageNet-shaped synthetic, resnet_kfilters
+    resnet18(k=1.5) student distilled from a ResNet-34-shaped teacher, 4-bit bucketed, first/last
+    tensors not quantized, DP over 8 GPUs) and configs[4] (kind='nmt': 2-layer LSTM seq2seq,
+    multi30k-shaped synthetic tokens, 4-bit quantized distillation, DP over 4 GPUs).  Data
+    parallel with the flat-gradient RCCL all-reduce, cut in 4 pieces overlapped with backward."""
+    import torch.distributed as dist
+    from harness import models
+    from harness.distill import (DistillTrainer, seq2seq_kd_loss_fn, synthetic_batch, synthetic_token_batch)
+    torch.manual_seed(0)
+    if kind == 'imagenet':
+        per_gpu = 32
+        tr = DistillTrainer(models.ResNetK((2, 2, 2, 2), 1.5), models.ResNetK((3, 4, 6, 3), 1.0), dev, num_bits=4,
+                            bucket_size=256, lr=0.1, weight_decay=1e-4, quantize_first_and_last_layer=False,
+                            grad_chunks=4, overlap_allreduce=True)
+        batches = [synthetic_batch(per_gpu, dev, seed=1000 * rank + i, classes=1000, side=224) for i in range(2)]
+        desc = ('ImageNet-shaped synthetic randn(B,3,224,224), 1000 classes; resnet18(k=1.5) student (62 tensors, 25.9 M) '
+                'distilled from a ResNet-34-shaped teacher; SGD nesterov lr 0.1 wd 1e-4; 4-bit uniform, bucket 256, '
+                'quantize_first_and_last_layer=False')
+    else:
+        per_gpu = 64
+        tr = DistillTrainer(models.Seq2SeqLSTM(), models.Seq2SeqLSTM(), dev, num_bits=4, bucket_size=256, lr=1.0,
+                            momentum=0.0, nesterov=False, weight_decay=0.0, loss_fn=seq2seq_kd_loss_fn, clip_norm=5.0,
+                            grad_chunks=4, overlap_allreduce=True)
+        batches = [synthetic_token_batch(per_gpu, dev, seed=1000 * rank + i) for i in range(2)]
+        desc = ('multi30k-shaped synthetic tokens (len 20..50, V_src 18000, V_tgt 10000), 2-layer LSTM 500/500 with input '
+                'feeding + general attention (22 tensors, 28.8 M), teacher of the same shape, word-level KD 0.3 NLL + 0.7 KL; '
+                'SGD lr 1.0, clip-norm 5; 4-bit uniform, bucket 256')
+    for i in range(warmup):
+        tr.step(*batches[i % 2])
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(*batches[i % 2])
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    phases = {}
+
+    def timed(name, fn, reps=5):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        phases[name] = round((time.perf_counter() - a) / reps * 1e3, 3)
+    timed('quantize_ms', tr.quantize)
+    timed('fwd_bwd_ms (+overlapped all-reduce launch)', lambda: (tr.forward_backward(*batches[0]), tr.sync.sync()))
+    timed('optimizer_ms', tr.opt.step)
+    out = {'config': desc, 'per_gpu_batch': per_gpu, 'global_batch': per_gpu * n_gpus, 'n_gpus': n_gpus,
+           'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2),
+           'samples_per_sec': round(steps * per_gpu * n_gpus / dt, 1), 'steps': steps, 'phases': phases,
+           'gradient_bytes_per_step': int(tr.flat_grad.numel() * 4)}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def diffquant_steps_per_sec(dev, steps=8, warmup=2, batch=100):
     """BASELINE configs[2]: CIFAR10 WideResNet-16-22 student (60 tensors, 82.7 M parameters), 2-bit
     (k = 4 points) non-uniform differentiable quantization, bucket 256, 1 GPU: steps/sec of the
@@ -371,6 +438,11 @@ def main():
         if n_gpus == 1 and not args.no_diffquant:
             torch.cuda.empty_cache()
             distill['diffquant_wrn'] = diffquant_steps_per_sec(dev)
+        # configs[3] is quoted on 8 GPUs, configs[4] on 4: run them where BASELINE.json places them
+        if n_gpus == 8 or os.environ.get('QD_BENCH_CFG4') == '1':
+            distill['imagenet_resnet18k_dp'] = dp_config_steps_per_sec('imagenet', dev, rank, n_gpus, distributed)
+        if n_gpus == 4 or os.environ.get('QD_BENCH_CFG5') == '1':
+            distill['nmt_lstm_dp'] = dp_config_steps_per_sec('nmt', dev, rank, n_gpus, distributed)
 
     if rank == 0:
         bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM

@@ -28,7 +28,8 @@ from .flat import FlatLayout, GradSynchronizer
 class DistillTrainer(object):
     def __init__(self, student, teacher, device, num_bits=4, bucket_size=256, lr=1e-3, momentum=0.9,
                  weight_decay=2.2e-4, nesterov=True, quantize_first_and_last_layer=True, mode='multi',
-                 backprop_quantization_style='none', grad_chunks=1):
+                 backprop_quantization_style='none', grad_chunks=1, overlap_allreduce=False, loss_fn=None,
+                 clip_norm=None):
         self.device = device
         self.student = student.to(device).train()
         self.teacher = teacher.to(device).eval()
@@ -68,6 +69,10 @@ class DistillTrainer(object):
         self.opt = torch.optim.SGD([self.flat_master], lr=lr, momentum=momentum, nesterov=nesterov,
                                    weight_decay=weight_decay)
         self.sync = GradSynchronizer(self.flat_grad, chunks=grad_chunks)
+        if overlap_allreduce:
+            self.sync.attach(params, layout)
+        self.loss_fn = loss_fn if loss_fn is not None else cnn_kd_loss_fn
+        self.clip_norm = clip_norm
 
     # ------------------------------------------------------------------ pieces of a step
     def quantize(self):
@@ -85,22 +90,26 @@ class DistillTrainer(object):
             for i, p in enumerate(self.params):
                 p.data = self.masters[i]
 
-    def forward_backward(self, images, labels):
+    def forward_backward(self, *batch):
         self.flat_grad.zero_()
-        out = self.student(images)
-        with torch.no_grad():
-            t_out = self.teacher(images)
-        loss = models.kd_loss(out, t_out, labels)
+        loss = self.loss_fn(self.student, self.teacher, *batch)
         loss.backward()
         return loss
 
-    def step(self, images, labels):
+    def clip(self):
+        """Global gradient-norm clipping on the flat buffer, no host sync (ref: onmt/Optim.py:40-55)."""
+        if self.clip_norm is not None:
+            norm = self.flat_grad.norm()
+            self.flat_grad.mul_((self.clip_norm / (norm + 1e-6)).clamp(max=1.0))
+
+    def step(self, *batch):
         if self._graph_fb is not None:
-            return self._step_graph(images, labels)
+            return self._step_graph(*batch)
         self.quantize()
-        loss = self.forward_backward(images, labels)
+        loss = self.forward_backward(*batch)
         self.restore()
         self.sync.sync()
+        self.clip()
         self.opt.step()
         return loss
 
@@ -138,6 +147,35 @@ class DistillTrainer(object):
         self.sync.sync()
         self._graph_opt.replay()
         return self._sloss
+
+
+def cnn_kd_loss_fn(student, teacher, images, labels):
+    """Student + teacher forward and the Hinton KD loss (ref: cnn_models/help_fun.py:60-158)."""
+    out = student(images)
+    with torch.no_grad():
+        t_out = teacher(images)
+    return models.kd_loss(out, t_out, labels)
+
+
+def seq2seq_kd_loss_fn(student, teacher, src, tgt):
+    """Teacher-forced student + teacher forward and the word-level KD loss
+    (ref: translation_models/help_fun.py:36-84, onmt/Loss.py:97-120).  src, tgt: (len, batch)."""
+    tgt_in, tgt_out = tgt[:-1], tgt[1:]
+    logits = student(src, tgt_in)
+    with torch.no_grad():
+        t_logits = teacher(src, tgt_in)
+    return models.word_kd_loss(logits, t_logits, tgt_out.flatten(), src.size(1))
+
+
+def synthetic_token_batch(batch, device, seed=0, v_src=18000, v_tgt=10000, max_len=50):
+    """multi30k-shaped synthetic batch: sequence-first int64 (len <= 50, batch), pad id 1."""
+    g = torch.Generator().manual_seed(seed)
+    s_len = int(torch.randint(20, max_len + 1, (1,), generator=g))
+    t_len = int(torch.randint(20, max_len + 1, (1,), generator=g))
+    src = torch.randint(2, v_src, (s_len, batch), generator=g)
+    tgt = torch.randint(2, v_tgt, (t_len, batch), generator=g)
+    tgt[-3:, ::4] = 1                                    # some padded tails
+    return src.to(device), tgt.to(device)
 
 
 def synthetic_batch(batch, device, seed=0, classes=10, side=32):

@@ -25,29 +25,77 @@ class FlatLayout(object):
 
 
 class GradSynchronizer(object):
-    """Data-parallel gradient exchange: ONE all-reduce (sum) of the flat fp32 gradient buffer per
-    step, then a scale by 1/world -- the MI355X-native stand-in for nn.DataParallel's
-    reduce-to-GPU0 + broadcast.  Over RCCL/xGMI on GPUs ("nccl" backend),
-    over gloo in the CPU tests.  `chunks` > 1 splits the buffer into that many contiguous
-    all-reduces (large models: lets the first chunks overlap the rest of backward when issued
-    from hooks; a single call otherwise)."""
+    """Data-parallel gradient exchange: all-reduce (sum) of the flat fp32 gradient buffer, then a
+    scale by 1/world -- the MI355X-native stand-in for nn.DataParallel's reduce-to-GPU0 +
+    broadcast.  Over RCCL/xGMI on GPUs ("nccl" backend), over gloo in the CPU
+    tests.
+
+    chunks == 1: ONE all-reduce of the whole buffer after backward (small models).
+    chunks  > 1: the buffer is cut at parameter boundaries into `chunks` contiguous pieces; with
+    attach() every piece is all-reduced asynchronously AS SOON AS the gradients of all its
+    parameters have been accumulated, i.e. overlapped with the rest of backward (autograd
+    produces gradients roughly in reverse parameter order, so the last piece goes first).
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large pieces keep every link busy
+    without paying the per-collective latency of hundreds of per-tensor reductions."""
 
     def __init__(self, flat_grad, group=None, chunks=1):
         self.flat_grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         n = flat_grad.numel()
-        chunks = max(1, min(chunks, n))
-        step = -(-n // chunks)
+        self.chunks = max(1, min(chunks, n))
+        step = -(-n // self.chunks)
         self.bounds = [(i, min(i + step, n)) for i in range(0, n, step)]
+        self._pending = None
+        self._handles = []
+        self._launched = []
+
+    def attach(self, params, layout):
+        """Overlap mode: register post-accumulate hooks on `params` (laid out by `layout`)."""
+        total_params = len(params)
+        per = -(-total_params // self.chunks)
+        groups = [list(range(i, min(i + per, total_params))) for i in range(0, total_params, per)]
+        self.bounds = []
+        for g in groups:
+            a = layout.offsets[g[0]]
+            last = g[-1]
+            b = layout.offsets[last + 1] if last + 1 < total_params else layout.total
+            self.bounds.append((a, b))
+        self._group_sizes = [len(g) for g in groups]
+        self._pending = list(self._group_sizes)
+        self._launched = [False] * len(groups)
+        if self.world == 1:
+            return
+        for c, g in enumerate(groups):
+            for i in g:
+                params[i].register_post_accumulate_grad_hook(lambda _p, c=c: self._ready(c))
+
+    def _launch(self, c):
+        a, b = self.bounds[c]
+        self._handles.append(dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True))
+        self._launched[c] = True
+
+    def _ready(self, c):
+        self._pending[c] -= 1
+        if self._pending[c] == 0 and not self._launched[c]:
+            self._launch(c)
 
     def sync(self):
         if self.world == 1:
             return
-        handles = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                   for a, b in self.bounds]
-        for h in handles:
+        if self._pending is None:                       # no hooks: everything now
+            self._handles = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True) for a, b in self.bounds]
+        else:
+            for c in range(len(self.bounds)):           # pieces whose parameters got no gradient this step
+                if not self._launched[c]:
+                    self._launch(c)
+            self._pending = list(self._group_sizes)
+            self._launched = [False] * len(self.bounds)
+        for h in self._handles:
             h.wait()
+        self._handles = []
         self.flat_grad.mul_(1.0 / self.world)
 
 

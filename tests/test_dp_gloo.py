@@ -39,13 +39,20 @@ def _worker(rank, world, port, chunks, out_dir):
     net.eval()                                             # BN in eval mode: the loss is a plain mean over samples
     loss = torch.nn.functional.cross_entropy(net(images[lo:hi]), labels[lo:hi])
     loss.backward()
-    GradSynchronizer(flat_grad, chunks=chunks).sync()
+    sync = GradSynchronizer(flat_grad, chunks=abs(chunks))
+    if chunks < 0:                                         # negative = overlap mode: hooks fire during backward
+        flat_grad.zero_()
+        sync.attach(params, layout)
+        net.zero_grad(set_to_none=False)
+        loss = torch.nn.functional.cross_entropy(net(images[lo:hi]), labels[lo:hi])
+        loss.backward()
+    sync.sync()
     torch.save(flat_grad, os.path.join(out_dir, 'grad_rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('chunks', [1, 3])
+@pytest.mark.parametrize('chunks', [1, 3, -4])
 def test_allreduced_gradient_equals_single_process(tmp_path, chunks):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), chunks, str(tmp_path)), nprocs=world, join=True)
