@@ -1314,7 +1314,7 @@ int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64
     if (aligned && nfull > 0) {
         if (row == 64) QD_STE(16, 1)
         else if (row == 128) QD_STE(16, 2)
-        else if (row == 256) QD_STE(16, 4)
+        else if (row == 256) QD_STE(16, 4)      // whole-wave (64,1) variant measured no faster (tools/ notes)
         else if (row == 512) QD_STE(64, 2)
         else if (row == 1024) QD_STE(64, 4)
     }

@@ -58,13 +58,45 @@ def assign_bits_automatically(gradient_norms, inital_bits_to_assign, input_is_po
     return alloc
 
 
+def percentile_points_from_sorted(fetch, n, num_points):
+    """np.percentile(a, np.linspace(0, 100, num_points)) (method 'linear', float32 data) given only
+    random access to the SORTED data: `fetch(int64 index array) -> float32 values`.  Reproduces
+    numpy's arithmetic exactly (virtual index (n-1)*q with q = p/float32(100); float32 difference
+    of the two neighbours; float64 lerp with the t >= 0.5 branch of numpy's _lerp), so the result is
+    bit-identical to the reference's host-side call (ref: help_functions.py:150) while only
+    2*num_points values ever leave the device."""
+    quant = np.true_divide(np.linspace(0, 100, num=num_points), np.float32(100))
+    virtual = (n - 1) * quant
+    lower = np.floor(virtual)
+    upper = lower + 1
+    at_end = virtual >= n - 1
+    lower[at_end] = n - 1
+    upper[at_end] = n - 1
+    gamma = virtual - np.floor(virtual)
+    a = np.asarray(fetch(lower.astype(np.int64)), dtype=np.float32)
+    b = np.asarray(fetch(upper.astype(np.int64)), dtype=np.float32)
+    diff = np.subtract(b, a)
+    result = np.add(a, diff * gamma)
+    np.subtract(b, diff * (1 - gamma), out=result, where=gamma >= 0.5)
+    return result
+
+
 def initialize_quantization_points(tensor, scaling_function, num_points):
     """Starting points for the non-uniform optimisation: the `num_points` evenly spaced
-    percentiles of the scaled tensor.  ref: help_functions.py:140-154.  The scaling runs on the
-    device (K2); the percentile itself is the reference's host-side np.percentile (setup path,
-    once per tensor)."""
+    percentiles of the scaled tensor.  ref: help_functions.py:140-154.
+
+    The reference copies the whole scaled tensor to the host and runs np.percentile there.  Here
+    the scaling (K2) and the sort run on the device and only the 2*num_points order statistics
+    the interpolation needs are copied back; the interpolation itself is numpy's, so the result
+    is bit-identical (tests/golden/misc.npz)."""
+    n = tensor.numel()
     scaled = scaling_function.scale_down(tensor).view(-1)[0:scaling_function.original_tensor_length]
-    values = np.percentile(scaled.cpu().numpy(), np.linspace(0, 100, num=num_points))
+    ordered = torch.sort(scaled)[0]
+
+    def fetch(index):
+        return ordered[torch.from_numpy(index).to(ordered.device)].cpu().numpy()
+
+    values = percentile_points_from_sorted(fetch, n, num_points)
     return torch.from_numpy(values).type_as(tensor).to(tensor.device)
 
 

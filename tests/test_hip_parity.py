@@ -377,3 +377,57 @@ def test_c_abi_argument_errors():
                               None, 0, _lib.stream_ptr()) == -2  # global path needs the workspace
     with pytest.raises(RuntimeError):
         _lib.check(-2)
+
+
+def test_beyond_int32_elements():
+    """Maximum sizes: a tensor with more than 2^31 elements (8.6 GB in, 8.6 GB out) exercises the
+    64-bit indexing of every path.  Checked by a size-independent property: quantizing the whole
+    tensor equals quantizing bucket-aligned pieces, and the pieces are checked against the C
+    oracle on sampled windows."""
+    n = (1 << 31) + 256 * 3 + 17                    # ragged, > INT32_MAX
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * n * 4 + (4 << 30):
+        pytest.skip('not enough free HBM for the 2^31-element test')
+    x = torch.empty(n, device=DEV)
+    piece = 1 << 28
+    g = torch.Generator(device=DEV).manual_seed(7)
+    for lo in range(0, n, piece):
+        x[lo:lo + piece].normal_(generator=g)
+    q, sf = quantization.uniformQuantization(x, 16, bucket_size=256)
+    assert sf.alpha.shape == ((n + 255) // 256, 1)
+    # windows at the start, across the 2^31 boundary and the ragged tail, against the oracle
+    for lo in (0, (1 << 31) - 256 * 4, n - (n % 256) - 256 * 2):
+        hi = min(n, lo + 256 * 8)
+        want = oc.uniform_quantize(host(x[lo:hi]), 16, 256, want_idx=False, want_lev=False)['q']
+        assert np.array_equal(host(q[lo:hi]), want), lo
+    # whole == pieces (bucket-aligned split)
+    cut = (1 << 31) + 256
+    qa, _ = quantization.uniformQuantization(x[:cut], 16, bucket_size=256)
+    assert torch.equal(qa, q[:cut])
+    del qa
+    qb, _ = quantization.uniformQuantization(x[cut:], 16, bucket_size=256)
+    assert torch.equal(qb, q[cut:])
+    del qb, q
+    # un-bucketed path (global reduce + apply) and the nearest-point path on the same tensor
+    qg, sfg = quantization.uniformQuantization(x, 4)
+    mn, mx = x.min(), x.max()
+    assert float(sfg.beta) == float(mn) and float(sfg.alpha) == float(mx - mn)
+    assert torch.equal(qg[-5:], quantization.uniformQuantization(x, 4)[0][-5:])
+    lev = torch.round((qg[-1000:] - sfg.beta) / sfg.alpha * 3)
+    assert float(lev.min()) >= 0 and float(lev.max()) <= 3
+    del qg
+    pts = torch.tensor([0.0, 0.4, 0.6, 1.0], device=DEV)
+    fn = quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=x)
+    qn = fn.forward(None, pts)
+    idx = fn.savedForBackward.raw_indices()
+    assert idx.dtype == torch.uint8 and idx.numel() == n
+    hist = torch.bincount(idx[-100000:].long(), minlength=4)
+    assert int(hist.sum()) == 100000
+    lo = (1 << 31) - 512
+    r = oc.nonuniform_quantize(host(x[lo:lo + 2048]), host(pts), 256, 'midpoint')
+    assert np.array_equal(host(qn[lo:lo + 2048]), r['q']) and np.array_equal(host(idx[lo:lo + 2048]).astype(np.int64), r['idx'])
+    gsum = fn.backward(torch.ones_like(x))[1]
+    # sum over bins of grad = sum_i alpha_bucket(i) (g = 1): compare with 256 * sum(alpha) minus the ragged remainder
+    al = fn.scaling_function.alpha.view(-1).double()
+    want = float(al[:-1].sum() * 256 + al[-1] * (n % 256))
+    assert abs(float(gsum.double().sum()) - want) <= 1e-5 * want

@@ -107,3 +107,18 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.QdLibraryMissing):
         _lib.load()
+
+
+def test_percentile_from_sorted_is_numpy_exact():
+    """The 2k-order-statistics percentile used by initialize_quantization_points reproduces
+    np.percentile (what the reference calls, help_functions.py:150) bit for bit."""
+    rng = np.random.RandomState(0)
+    for trial in range(600):
+        n = int(rng.choice([1, 2, 3, 5, 10, 100, 1000, 4097, 100003]))
+        k = int(rng.choice([2, 3, 4, 7, 8, 16, 64, 256]))
+        x = rng.rand(n).astype(np.float32)
+        if trial % 3 == 0:
+            x = np.round(x * 8) / 8
+        s = np.sort(x)
+        got = qhf.percentile_points_from_sorted(lambda i: s[i], n, k)
+        assert np.array_equal(got, np.percentile(x, np.linspace(0, 100, num=k))), (n, k)
