@@ -150,6 +150,24 @@ int64_t qd_multi_plan(QdTensorDesc* host_table, int ntensors, int64_t bucket);
 int qd_multi_uniform_f32(const QdTensorDesc* table, int ntensors, int64_t total_tiles, int64_t bucket, int levels,
                          void* stream);
 
+/* ---- packed-index codec (the compressed form whose SIZE the reference accounts for in
+ * helpers/functions.py:226-262: bits*N/8 bytes of level indices + 8 bytes (alpha, beta) per
+ * bucket) and the level histogram behind the Huffman accounting of
+ * quantization/help_functions.py:175-232.
+ * qd_pack_uniform_f32: quantize x with `levels` levels per bucket and store ONLY the level
+ *   indices, `bits` (1, 2, 4 or 8; levels <= 2^bits) per element, element e in bits
+ *   [e*bits, (e+1)*bits) of `packed` (qd_packed_bytes(n, bits) bytes, little endian inside a byte),
+ *   plus alpha/beta [num_buckets].  bucket in {64,128,256,512,1024,2048}; x 16-byte aligned.
+ * qd_unpack_uniform_f32: y = (index/(levels-1))*alpha + beta -- bit-identical to the output of
+ *   qd_uniform_f32 on the same input.  bucket: any power of two >= 8.
+ * qd_histogram_u8: hist[j] = #{i : idx[i] == j}, j < k <= 256 (hist is overwritten). */
+int64_t qd_packed_bytes(int64_t n, int bits);
+int qd_pack_uniform_f32(const float* x, int64_t n, int64_t bucket, int levels, int bits, uint8_t* packed, float* alpha,
+                        float* beta, void* stream);
+int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int levels, int bits, const float* alpha,
+                          const float* beta, float* y, void* stream);
+int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,10 @@ SIGNATURES = {
     'qd_truncated_ste_f32': (c_int, [c_f, c_f, i64, c_float, c_p]),
     'qd_multi_plan': (i64, [ctypes.POINTER(QdTensorDesc), c_int, i64]),
     'qd_multi_uniform_f32': (c_int, [c_p, c_int, i64, i64, c_int, c_p]),
+    'qd_packed_bytes': (i64, [i64, c_int]),
+    'qd_pack_uniform_f32': (c_int, [c_f, i64, i64, c_int, c_int, c_p, c_f, c_f, c_p]),
+    'qd_unpack_uniform_f32': (c_int, [c_p, i64, i64, c_int, c_int, c_f, c_f, c_f, c_p]),
+    'qd_histogram_u8': (c_int, [c_p, i64, c_int, c_p, c_p]),
 }
 
 

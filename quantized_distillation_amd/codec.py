@@ -1,0 +1,103 @@
+"""Packed representation of uniformly quantized tensors and device-side size accounting.
+
+The reference only *accounts* for the compressed size of a quantized model
+(ref: helpers/functions.py:216-262 -- `bits*N/8` bytes of level indices + 8 bytes per bucket --
+and quantization/help_functions.py:175-232 for the Huffman mean code length); it never builds
+the compressed form.  This module builds it on the device (qd_pack_uniform_f32), decodes it back
+to exactly the tensor uniformQuantization returns (qd_unpack_uniform_f32), and computes the level
+histogram / Huffman length without copying tensors to the host (qd_histogram_u8).
+"""
+import torch
+
+from . import _lib
+from .quantization.help_functions import huffman_encode
+
+
+def bits_for_levels(s):
+    for b in (1, 2, 4, 8):
+        if s <= (1 << b):
+            return b
+    raise ValueError('the packed format holds at most 256 levels')
+
+
+class PackedUniform(object):
+    """`bits`-per-element level indices + per-bucket (alpha, beta) of one tensor."""
+
+    def __init__(self, packed, alpha, beta, shape, s, bucket_size, bits):
+        self.packed, self.alpha, self.beta = packed, alpha, beta
+        self.shape, self.s, self.bucket_size, self.bits = torch.Size(shape), s, bucket_size, bits
+
+    @property
+    def nbytes(self):
+        """Bytes of the compressed form: what helpers/functions.py:255-259 charges for it."""
+        return self.packed.numel() + 4 * (self.alpha.numel() + self.beta.numel())
+
+    def unpack(self):
+        """The fake-quantized fp32 tensor, bit-identical to uniformQuantization(x, s, bucket)[0]."""
+        n = self.shape.numel()
+        y = torch.empty(n, dtype=torch.float32, device=self.packed.device)
+        if n > 0:
+            _lib.check(_lib.load().qd_unpack_uniform_f32(self.packed.data_ptr(), n, self.bucket_size, self.s, self.bits,
+                                                         self.alpha.data_ptr(), self.beta.data_ptr(), y.data_ptr(),
+                                                         _lib.stream_ptr()))
+        return y.view(self.shape)
+
+
+def pack_uniform(tensor, s, bucket_size=256, bits=None):
+    """Quantize `tensor` with `s` levels per bucket and keep only the packed level indices."""
+    _lib.require_device_f32(tensor)
+    if bucket_size not in (64, 128, 256, 512, 1024, 2048):
+        raise ValueError('the packed format is defined for bucket sizes 64..2048 (powers of two)')
+    bits = bits_for_levels(s) if bits is None else bits
+    x = tensor.contiguous()
+    n = x.numel()
+    lib = _lib.load()
+    nb = max(1, -(-n // bucket_size))
+    packed = torch.empty(int(lib.qd_packed_bytes(n, bits)) + 8, dtype=torch.uint8, device=x.device)[:int(lib.qd_packed_bytes(n, bits))]
+    ab = torch.empty(2, nb, dtype=torch.float32, device=x.device)
+    if n > 0:
+        _lib.check(lib.qd_pack_uniform_f32(x.data_ptr(), n, bucket_size, int(s), bits, packed.data_ptr(),
+                                           ab[0].data_ptr(), ab[1].data_ptr(), _lib.stream_ptr()))
+    return PackedUniform(packed, ab[0], ab[1], tensor.shape, int(s), bucket_size, bits)
+
+
+def histogram_u8(idx, k):
+    """Counts of the symbols 0..k-1 in a uint8 device tensor, as an int64 device tensor [k]."""
+    if idx.dtype != torch.uint8 or not idx.is_cuda:
+        raise TypeError('histogram_u8 needs a uint8 tensor on a HIP device')
+    idx = idx.contiguous()
+    hist = torch.empty(k, dtype=torch.int64, device=idx.device)
+    _lib.check(_lib.load().qd_histogram_u8(idx.data_ptr(), idx.numel(), int(k), hist.data_ptr(), _lib.stream_ptr()))
+    return hist
+
+
+def level_histogram(tensor, s, bucket_size=None):
+    """Histogram of the quantization levels of `tensor` (s <= 256), computed on the device: the
+    level index is a side output of the quantize kernel (1 B/element), then one counting pass."""
+    _lib.require_device_f32(tensor)
+    x = tensor.contiguous().view(-1)
+    n = x.numel()
+    lev = torch.empty(n, dtype=torch.uint8, device=x.device)
+    q = torch.empty_like(x)
+    ws = _lib.workspace(x.device)
+    if n > 0:
+        _lib.check(_lib.load().qd_uniform_f32(x.data_ptr(), q.data_ptr(), n, 0 if bucket_size is None else bucket_size,
+                                              int(s), None, None, lev.data_ptr(), None, 0, 0.0, 0, 0, ws.data_ptr(),
+                                              ws.numel(), _lib.stream_ptr()))
+    return histogram_u8(lev, s)
+
+
+def huffman_mean_bit_length_uniform(params, s, bucket_size=None):
+    """Mean Huffman code length (bits/weight) of the level indices of a model, as
+    get_huffman_encoding_mean_bit_length(..., 'uniform', s) computes it
+    (ref: help_functions.py:175-232), with the histogram built on the device: only s counters per
+    model cross PCIe instead of every quantized tensor."""
+    total = None
+    for p in params:
+        t = p.data if hasattr(p, 'data') else p
+        h = level_histogram(t, s, bucket_size)
+        total = h if total is None else total + h
+    counts = total.cpu().tolist()
+    n = sum(counts)
+    freq = {j: c / n for j, c in enumerate(counts) if c > 0}
+    return sum(freq[sym] * len(code) for sym, code in huffman_encode(freq))

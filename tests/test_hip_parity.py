@@ -431,3 +431,50 @@ def test_beyond_int32_elements():
     al = fn.scaling_function.alpha.view(-1).double()
     want = float(al[:-1].sum() * 256 + al[-1] * (n % 256))
     assert abs(float(gsum.double().sum()) - want) <= 1e-5 * want
+
+
+# ------------------------------------------------------------------------------ packed codec + histograms
+@pytest.mark.parametrize('s,bits', [(2, 1), (4, 2), (3, 2), (16, 4), (9, 4), (256, 8), (16, 8)])
+def test_pack_unpack_roundtrip(s, bits):
+    from quantized_distillation_amd import codec
+    rng = np.random.RandomState(s)
+    for n, bucket in [(256 * 40, 256), (100003, 256), (70001, 64), (5 * 2048 + 7, 2048), (300, 256), (1 << 22, 512)]:
+        x = rng.randn(n).astype(np.float32)
+        xd = dev(x)
+        pk = codec.pack_uniform(xd, s, bucket, bits=bits)
+        ref = oc.uniform_quantize(x, s, bucket)
+        # packed bytes == numpy packing of the oracle's level indices (little endian inside a byte)
+        lev = ref['lev'].astype(np.uint64)
+        epb = 8 // bits
+        pad = (-n) % epb
+        levp = np.concatenate([lev, np.zeros(pad, np.uint64)]).reshape(-1, epb)
+        want = np.zeros(levp.shape[0], np.uint64)
+        for c in range(epb):
+            want |= levp[:, c] << np.uint64(c * bits)
+        assert np.array_equal(host(pk.packed), want.astype(np.uint8)), (n, bucket)
+        assert np.array_equal(host(pk.alpha), ref['alpha']) and np.array_equal(host(pk.beta), ref['beta'])
+        # decode == uniformQuantization, bit for bit
+        y = pk.unpack()
+        q, _ = quantization.uniformQuantization(xd, s, bucket_size=bucket)
+        assert torch.equal(y, q) and np.array_equal(host(y), ref['q'])
+        # size = what helpers/functions.py:255-259 charges: bits*N/8 + 8 bytes per bucket
+        assert pk.nbytes == (n * bits + 7) // 8 + 8 * (-(-n // bucket))
+
+
+def test_level_histogram_and_device_huffman(golden_misc):
+    from quantized_distillation_amd import codec
+    rng = np.random.RandomState(1)
+    for n, s, bucket in [(100003, 16, 256), (1 << 20, 4, None), (5000, 256, 256), (77, 2, 256)]:
+        x = rng.randn(n).astype(np.float32)
+        h = codec.level_histogram(dev(x), s, bucket)
+        assert np.array_equal(host(h), np.bincount(oc.uniform_quantize(x, s, bucket)['lev'], minlength=s)), (n, s, bucket)
+    idx = rng.randint(0, 200, size=1 << 21).astype(np.uint8)
+    assert np.array_equal(host(codec.histogram_u8(dev(idx), 256)), np.bincount(idx, minlength=256))
+    assert np.array_equal(host(codec.histogram_u8(dev(idx[3:]), 256)), np.bincount(idx[3:], minlength=256))   # unaligned
+    # same Huffman mean code length as the reference computed through its digitize path
+    G = golden_misc
+    params = [dev(G.z['hf_p%d' % j]) for j in range(4)]
+    for c in G.meta['huffman']:
+        if c['kind'] == 'uniform':
+            got = codec.huffman_mean_bit_length_uniform(params, c['s'], c['bucket'])
+            assert abs(got - c['mean_bit_length']) < 1e-12, (c, got)

@@ -114,6 +114,17 @@ timeit("K7  'complicated' STE backward bucket 256", k7, 12)
 timeit("K8  truncated STE grad mask", lambda i: lib.qd_truncated_ste_f32(xs[i % R].data_ptr(), gs[i % R].data_ptr(), N, 1.0, _lib.stream_ptr()), 8,
        note='4 B w read + 4 B g write where masked (<= 12)')
 
+from quantized_distillation_amd import codec  # noqa: E402
+pks = [None] * R
+timeit('PK  pack 4-bit levels + alpha/beta, bucket 256', lambda i: pks.__setitem__(i % R, codec.pack_uniform(xs[i % R], 16, 256)), 4.5,
+       note='4 B read + 0.5 B written')
+pk0 = codec.pack_uniform(xs[0], 16, 256)
+timeit('UPK unpack 4-bit -> fp32, bucket 256', lambda i: live.__setitem__(i % R, pk0.unpack()), 4.5, note='0.5 B read + 4 B written')
+lev8 = [torch.randint(0, 16, (N,), dtype=torch.uint8, device=dev) for _ in range(R)]
+timeit('HST histogram of uint8 levels, k=16', lambda i: codec.histogram_u8(lev8[i % R], 16), 1)
+timeit('HST histogram of uint8 levels, k=256', lambda i: codec.histogram_u8(lev8[i % R], 256), 1)
+del lev8, pks, pk0
+
 # multi-tensor over a Wide_ResNet-16-22-like set of shapes (60 tensors, 82.7 M params)
 shapes = [(16, 3, 3, 3), (16,)]
 w = [16, 352, 704, 1408]
