@@ -102,44 +102,47 @@ __global__ __launch_bounds__(64) void k_pack_tail(const float* x, uint8_t* packe
     }
 }
 
-// decode: each thread expands 8 consecutive elements (BITS bytes) into two float4
+// decode: each thread expands 4 consecutive elements into ONE float4 (lanes contiguous: a wave
+// writes 1 KiB per store instruction); the packed read is 4*BITS bits per lane
 template <int BITS>
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, float* y, const float* alpha, const float* beta,
                                                 int64_t n, int row_shift, float sm1) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    const int64_t ngroups = (n + 7) >> 3;
+    const int64_t ngroups = (n + 3) >> 2;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const bool y_vec = (((uintptr_t)y) & 15) == 0;
     for (int64_t gI = tid; gI < ngroups; gI += nth) {
-        const int64_t e0 = gI << 3;
+        const int64_t e0 = gI << 2;
         const int64_t bkt = e0 >> row_shift;
         const float a = alpha[bkt], b = beta[bkt];
-        uint64_t bits = 0;
-        const uint8_t* src = packed + gI * BITS;
-        if (e0 + 8 <= n) {
-            if (BITS == 8) bits = *(const uint64_t*)src;
-            else if (BITS == 4) bits = *(const uint32_t*)src;
-            else if (BITS == 2) bits = *(const uint16_t*)src;
-            else bits = *src;
+        uint32_t bits;
+        const bool full = e0 + 4 <= n;
+        if (BITS == 8) {
+            if (full) bits = *(const uint32_t*)(packed + e0);
+            else { bits = 0; for (int64_t c = 0; e0 + c < n; ++c) bits |= (uint32_t)packed[e0 + c] << (8 * c); }
+        } else if (BITS == 4) {
+            if (full) bits = *(const uint16_t*)(packed + (e0 >> 1));
+            else { bits = packed[e0 >> 1]; if (e0 + 2 < n) bits |= (uint32_t)packed[(e0 >> 1) + 1] << 8; }
+        } else if (BITS == 2) {
+            bits = packed[e0 >> 2];
         } else {
-            const int64_t nb = (((n - e0) * BITS) + 7) >> 3;
-            for (int64_t k = 0; k < nb; ++k) bits |= (uint64_t)src[k] << (8 * k);
+            bits = (uint32_t)packed[e0 >> 3] >> (e0 & 4);      // low or high nibble of the shared byte
         }
-        float out[8];
+        float out[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float r = (float)((uint32_t)(bits >> (c * BITS)) & MASK);
+        for (int c = 0; c < 4; ++c) {
+            const float r = (float)((bits >> (c * BITS)) & MASK);
             float w = r / sm1;                         // same three ops as the tail of qdq()
             float v = w * a;
             v = v + b;
             out[c] = v + 0.0f;
         }
-        if (e0 + 8 <= n && ((((uintptr_t)y) & 15) == 0)) {
-            f4 o0 = {out[0], out[1], out[2], out[3]}, o1 = {out[4], out[5], out[6], out[7]};
-            __builtin_nontemporal_store(o0, (f4*)(y + e0));
-            __builtin_nontemporal_store(o1, (f4*)(y + e0) + 1);
+        if (full && y_vec) {
+            f4 o = {out[0], out[1], out[2], out[3]};
+            __builtin_nontemporal_store(o, (f4*)(y + e0));
         } else {
-            for (int c = 0; c < 8 && e0 + c < n; ++c) y[e0 + c] = out[c];
+            for (int c = 0; c < 4 && e0 + c < n; ++c) y[e0 + c] = out[c];
         }
     }
 }
@@ -245,13 +248,13 @@ int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int 
         return QD_ERR_INVALID_ARGUMENT;
     if (n > 0 && (!packed || !y || !alpha || !beta)) return QD_ERR_INVALID_ARGUMENT;
     if (bucket < 8 || (bucket & (bucket - 1))) return QD_ERR_UNSUPPORTED;
-    if ((((uintptr_t)packed) & 7)) return QD_ERR_UNSUPPORTED;
+    if ((((uintptr_t)packed) & 3)) return QD_ERR_UNSUPPORTED;
     if (n == 0) return 0;
     int row_shift = 0;
     while (((int64_t)1 << row_shift) < bucket) ++row_shift;
     hipStream_t st = (hipStream_t)stream;
     const float sm1 = (float)(levels - 1);
-    const int blocks = blocks_for((n + 7) / 8, 256, 1 << 20);
+    const int blocks = blocks_for((n + 3) / 4, 256 * 4, 1 << 20);
     if (bits == 8) hipLaunchKernelGGL(k_unpack<8>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1);
     else if (bits == 4) hipLaunchKernelGGL(k_unpack<4>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1);
     else if (bits == 2) hipLaunchKernelGGL(k_unpack<2>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1);

@@ -196,6 +196,58 @@ __device__ __forceinline__ void bucket_lanes(const KParams& p, const PointTable*
     }
 }
 
+// Same, for a FULL bucket whose length is a multiple of 4 and whose base is 16-byte aligned:
+// float4 accesses (4x fewer memory instructions than the scalar routine).  Odd bucket sizes such
+// as 100 take this path; the second pass re-reads the bucket from L1/L2.
+template <int MODE, int LANES>
+__device__ __forceinline__ void bucket_lanes4(const KParams& p, const PointTable* T, int64_t bkt, int64_t lo,
+                                              int l, const Prep& pp) {
+    const int nv = (int)(p.row >> 2);
+    const f4* src = (const f4*)(p.x + lo);
+    f4* dst = (f4*)(p.out + lo);
+    const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    float a, b;
+    if (prescaled) {
+        a = p.alpha[bkt]; b = p.beta[bkt];
+    } else {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int i = l; i < nv; i += LANES) {
+            const f4 v = prep4(src[i], pp);
+            mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+            mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+        if (LANES == 16) { mn = row16_min(mn); mx = row16_max(mx); }
+        else { mn = wave_min(mn); mx = wave_max(mx); }
+        alpha_beta(mn, mx, a, b);
+        if (l == 0) {
+            if (p.alpha) p.alpha[bkt] = a;
+            if (p.beta) p.beta[bkt] = b;
+        }
+    }
+    for (int i = l; i < nv; i += LANES) {
+        f4 v = src[i];
+        if (!prescaled) v = prep4(v, pp);
+        const int64_t e = lo + ((int64_t)i << 2);
+        float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == MODE_QDQ && p.stochastic) {
+            // element index need not be a multiple of 4 here: draw per element from its own block
+            for (int c = 0; c < 4; ++c) {
+                float r4[4];
+                philox_uniform4(p.seed, (uint64_t)(e + c) >> 2, r4);
+                rnd[c] = r4[(e + c) & 3];
+            }
+        }
+        float side[4];
+        f4 r;
+        r.x = transform<MODE>(p, T, v.x, a, b, pp.mean, rnd[0], side[0]);
+        r.y = transform<MODE>(p, T, v.y, a, b, pp.mean, rnd[1], side[1]);
+        r.z = transform<MODE>(p, T, v.z, a, b, pp.mean, rnd[2], side[2]);
+        r.w = transform<MODE>(p, T, v.w, a, b, pp.mean, rnd[3], side[3]);
+        __builtin_nontemporal_store(r, dst + i);
+        for (int c = 0; c < 4; ++c) store_side1<MODE>(p, e + c, side[c]);
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable* T, int64_t bkt, int64_t lo,
                                              int64_t hi, int l, const Prep& pp) {
@@ -229,6 +281,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     for (int64_t t = wave; t < ntiles; t += nwaves) {
         const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
         f4 v[U][V];
+        float a_keep = 0.0f, b_keep = 0.0f;
 #pragma unroll
         for (int uu = 0; uu < U; ++uu) {
             if (bkt0 + uu < p.nvec) {
@@ -258,10 +311,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                     if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
                     else { mn = wave_min(mn); mx = wave_max(mx); }
                     alpha_beta(mn, mx, a, b);
-                    if (l == 0) {
-                        if (p.alpha) p.alpha[bkt] = a;
-                        if (p.beta) p.beta[bkt] = b;
-                    }
+                    if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
                 }
                 f4* dst = (f4*)(p.out + e0);
 #pragma unroll
@@ -279,6 +329,12 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                     store_side4<MODE>(p, e, side);
                 }
             }
+        }
+        // alpha/beta of the group's U buckets: lanes 0..U-1 write U consecutive floats (one store
+        // instruction per array per tile instead of U single-lane stores)
+        if (!prescaled && l < U && bkt0 + l < p.nvec) {
+            if (p.alpha) p.alpha[bkt0 + l] = a_keep;
+            if (p.beta) p.beta[bkt0 + l] = b_keep;
         }
     }
 
@@ -306,10 +362,12 @@ __global__ __launch_bounds__(256) void k_bucket_groups(KParams p) {
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / LANES;
     const int l = threadIdx.x % LANES;
+    const bool vec4 = (p.row & 3) == 0 && (((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) == 0);
     for (int64_t bkt = group; bkt < p.nb; bkt += ngroups) {
         const int64_t lo = bkt * p.row;
         const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
-        bucket_lanes<MODE, LANES>(p, T, bkt, lo, hi, l, pp);
+        if (vec4 && hi - lo == p.row) bucket_lanes4<MODE, LANES>(p, T, bkt, lo, l, pp);
+        else bucket_lanes<MODE, LANES>(p, T, bkt, lo, hi, l, pp);
     }
 }
 
@@ -994,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* table
                 r.y = qdq(v[j].y, a, b, sm1, 0.0f, lev);
                 r.z = qdq(v[j].z, a, b, sm1, 0.0f, lev);
                 r.w = qdq(v[j].w, a, b, sm1, 0.0f, lev);
-                dst[j * 16] = r;
+                __builtin_nontemporal_store(r, dst + j * 16);
             }
         } else {
             bucket_row16<MODE_QDQ>(p, nullptr, bkt, lo, hi, l, pp);
@@ -1083,7 +1141,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     }
 #undef QD_VEC
     p.nvec = 0;
-    if (p.row <= 48) {                                   // 16 buckets per block
+    if (p.row <= 256) {                                  // 16 buckets per block, a DPP row each
         hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16)), dim3(256), 0, st, p);
     } else if (p.row <= 16384) {                         // 4 buckets per block, one wave each
         hipLaunchKernelGGL((k_bucket_groups<MODE, 64>), dim3(blocks_for(p.nb, 4)), dim3(256), 0, st, p);
