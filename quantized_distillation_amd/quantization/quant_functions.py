@@ -124,10 +124,13 @@ class ScalingFunction(object):
         return tensor, n, nb, row
 
     def _alloc_alpha_beta(self, nb, device):
-        ab = torch.empty(2, nb, dtype=torch.float32, device=device)
-        shape = (1,) if self.bucket_size is None else (nb, 1)
-        self.alpha = ab[0].view(*shape)
-        self.beta = ab[1].view(*shape)
+        """One [2, nb] allocation; alpha/beta are its two rows, shaped (nb, 1) -- or (1,) without
+        buckets -- as the reference's min/max(keepdim=True) shapes them (ref: :85-92)."""
+        if self.bucket_size is None:
+            ab = torch.empty(2, 1, dtype=torch.float32, device=device)
+        else:
+            ab = torch.empty(2, nb, 1, dtype=torch.float32, device=device)
+        self.alpha, self.beta = ab.unbind(0)
         return ab
 
     def _note_arg_source(self, tensor, overwritten):
@@ -237,11 +240,18 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
         _STOCHASTIC_CALLS[0] += 1
         seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _STOCHASTIC_CALLS[0]) & 0xFFFFFFFFFFFFFFFF
     if n > 0:
-        ws = _lib.workspace(tensor.device)
-        _lib.check(_lib.load().qd_uniform_f32(
-            tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), ab[0].data_ptr(),
-            ab[1].data_ptr(), None, _ptr(scaling_function._mean_buf), clamp, me, 1 if stochastic_rounding else 0,
-            seed, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        if nb == 1:                       # only the single-bucket path needs the reduction scratch
+            ws = _lib.workspace(tensor.device)
+            ws_ptr, ws_len = ws.data_ptr(), ws.numel()
+        else:
+            ws_ptr, ws_len = None, 0
+        ab_ptr = ab.data_ptr()
+        rc = _lib.load().qd_uniform_f32(
+            tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), ab_ptr, ab_ptr + 4 * nb,
+            None, _ptr(scaling_function._mean_buf), clamp, me, 1 if stochastic_rounding else 0,
+            seed, ws_ptr, ws_len, _lib.stream_ptr(tensor.device))
+        if rc != 0:
+            _lib.check(rc)
     return out, scaling_function
 
 
@@ -292,11 +302,17 @@ def _nearest(x_ptr, prescaled, points, assign_mode, n, bucket_size, alpha, beta,
     q = torch.empty(n, dtype=torch.float32, device=device)
     idx = torch.empty(n, dtype=torch.int64 if idx_bytes == 8 else torch.uint8, device=device)
     if n > 0:
-        ws = _lib.workspace(device)
-        _lib.check(_lib.load().qd_nearest_point_f32(
+        if bucket_size is None or n < bucket_size:      # single bucket: the reduction scratch is needed
+            ws = _lib.workspace(device)
+            ws_ptr, ws_len = ws.data_ptr(), ws.numel()
+        else:
+            ws_ptr, ws_len = None, 0
+        rc = _lib.load().qd_nearest_point_f32(
             x_ptr, prescaled, points.data_ptr(), points.numel(), assign_mode, q.data_ptr(), idx.data_ptr(),
             idx_bytes, n, _bucket_arg(bucket_size), alpha.data_ptr(), beta.data_ptr(), _ptr(mean_buf), clamp, me,
-            ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+            ws_ptr, ws_len, _lib.stream_ptr(device))
+        if rc != 0:
+            _lib.check(rc)
     return q, idx
 
 
