@@ -681,8 +681,10 @@ template <int KR>
 struct PgBins {
     float acc[KR > 0 ? KR : 1];
     float* col;
-    __device__ __forceinline__ void init(float* lds_col) {
+    int stride;
+    __device__ __forceinline__ void init(float* lds_col, int stride_) {
         col = lds_col;
+        stride = stride_;
 #pragma unroll
         for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] = 0.0f;
     }
@@ -691,7 +693,7 @@ struct PgBins {
 #pragma unroll
             for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] += (id == j) ? m : 0.0f;
         } else {
-            col[id * 256] += m;                             // private column: plain LDS read-add-write
+            col[id * stride] += m;                          // private column: plain LDS read-add-write
         }
     }
 };
@@ -699,15 +701,18 @@ struct PgBins {
 template <int KR, int IDXB, bool BUCKETED>
 __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const void* idx, const float* alpha, int64_t n,
                                                          int row_shift, int k, float* part /* [grid][k] */) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // KR == 0: [k][256]; KR > 0: [4][KR]
+    // KR == 0: bins[k][BS] with BS = blockDim.x (256 for k <= 128, 128 for k <= 256, 64 for k <= 512:
+    // the table is at most 128 KiB of the CU's 160 KiB LDS); KR > 0: [4][KR]
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int BS = blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     if (KR == 0) {
-        for (int j = threadIdx.x; j < k * 256; j += 256) lds[j] = 0.0f;
+        for (int j = threadIdx.x; j < k * BS; j += BS) lds[j] = 0.0f;
         __syncthreads();
     }
     PgBins<KR> B;
-    B.init(lds + threadIdx.x);
+    B.init(lds + threadIdx.x, BS);
     const float a_single = BUCKETED ? 0.0f : alpha[0];
     const int64_t n4 = n >> 2;
     auto load4 = [&](int64_t i, f4& gv, int (&id)[4], float& a) {
@@ -753,18 +758,20 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
             if (lane == 0) lds[w * KR + j] = sum;
         }
         __syncthreads();
-        for (int j = threadIdx.x; j < k; j += 256)
+        for (int j = threadIdx.x; j < k; j += BS)
             part[(int64_t)blockIdx.x * k + j] = (lds[j] + lds[KR + j]) + (lds[2 * KR + j] + lds[3 * KR + j]);
     } else {
         __syncthreads();
-        // 4 threads per bin, 64 columns each, rotated start (bank-conflict free), then a fixed fold
-        for (int t = threadIdx.x; t < k * 4; t += 256) {
+        // 4 threads per bin, BS/4 columns each, rotated start (bank-conflict free), then a fixed fold
+        const int quarter = BS >> 2;
+        for (int t = threadIdx.x; t < ((k * 4 + 3) & ~3); t += BS) {
             const int j = t >> 2, q = t & 3;
             float acc = 0.0f;
-            for (int c = 0; c < 64; ++c) acc += lds[j * 256 + q * 64 + ((c + j) & 63)];
+            if (j < k)
+                for (int c = 0; c < quarter; ++c) acc += lds[j * BS + q * quarter + ((c + j) & (quarter - 1))];
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
-            if (q == 0) part[(int64_t)blockIdx.x * k + j] = acc;
+            if (q == 0 && j < k) part[(int64_t)blockIdx.x * k + j] = acc;
         }
     }
 }
@@ -1321,20 +1328,28 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     // partial rows of k floats each must fit the workspace's [kPartialBlocks * kMaxPoints] floats
     int blocks = blocks_for(n, 256 * 4 * 2);
     const int64_t max_rows = (int64_t)kPartialBlocks * kMaxPoints / k;
-    const int64_t cap = k <= 64 ? 8192 : 2048;
+    const int64_t cap = k <= 128 ? 8192 : 2048;
     if (blocks > cap) blocks = (int)cap;
     if (blocks > max_rows) blocks = (int)max_rows;
     int row_shift = 0;
     const bool pow2 = nb == 1 || (row & (row - 1)) == 0;
     if (nb > 1 && pow2) while (((int64_t)1 << row_shift) < row) ++row_shift;
     const bool idx_ok = idx_bytes == 8 ? ((((uintptr_t)idx) & 15) == 0) : ((((uintptr_t)idx) & 3) == 0);
-    const bool fast = k <= 64 && pow2 && idx_ok && ((((uintptr_t)g) & 15) == 0) && (nb == 1 || row >= 4);
+    const bool fast = k <= 512 && pow2 && idx_ok && ((((uintptr_t)g) & 15) == 0) && (nb == 1 || row >= 4);
     if (fast) {
+        // k <= 4: register bins; otherwise an LDS table [k][threads] of lane-private columns
+        const int threads = k <= 128 ? 256 : (k <= 256 ? 128 : 64);
+        const size_t lds_bytes = (size_t)(k <= 4 ? 4 * 4 : k * threads) * sizeof(float);
+        if (k > 128 && blocks > 2048) blocks = 2048;      // one resident block per CU: keep partial rows few
 #define QD_PG(KR, IDXB, BK)                                                                                         \
-        hipLaunchKernelGGL((k_point_grad_fast<KR, IDXB, BK>), dim3(blocks), dim3(256),                              \
-                           (size_t)(KR > 0 ? 4 * KR : k * 256) * sizeof(float), st, g, idx, alpha, n, row_shift, k, \
-                           w.pg_part)
-#define QD_PG_K(IDXB, BK) { if (k <= 4) QD_PG(4, IDXB, BK); else QD_PG(0, IDXB, BK); }
+        {                                                                                                           \
+            auto kern = k_point_grad_fast<KR, IDXB, BK>;                                                            \
+            if (lds_bytes > 64 * 1024)                                                                              \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(KR > 0 ? 256 : threads), lds_bytes, st, g, idx, alpha, n,   \
+                               row_shift, k, w.pg_part);                                                            \
+        }
+#define QD_PG_K(IDXB, BK) { if (k <= 4) QD_PG(4, IDXB, BK) else QD_PG(0, IDXB, BK) }
         if (idx_bytes == 8) { if (nb > 1) QD_PG_K(8, true) else QD_PG_K(8, false) }
         else { if (nb > 1) QD_PG_K(1, true) else QD_PG_K(1, false) }
 #undef QD_PG_K
