@@ -1,0 +1,73 @@
+"""Property-based GPU parity (hypothesis): random sizes, bucket sizes, level counts, value
+distributions and options, HIP path vs the C oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import quantization
+from oracle import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+buckets = st.sampled_from([None, 256, 256, 64, 128, 512, 1024, 2048, 4096, 100, 7, 1, 33, 1000])
+sizes = st.one_of(st.integers(1, 5000), st.integers(5000, 300000))
+levels = st.sampled_from([2, 3, 4, 7, 16, 16, 255, 256, 1000])
+
+
+def make(n, seed, kind):
+    rng = np.random.RandomState(seed)
+    if kind == 0:
+        x = rng.randn(n)
+    elif kind == 1:
+        x = rng.randn(n) * 1e-3 + 5.0
+    elif kind == 2:
+        x = rng.randint(-4, 5, size=n).astype(np.float64)          # ties everywhere
+    elif kind == 3:
+        x = np.full(n, 0.25)                                       # alpha guard
+    elif kind == 4:
+        x = rng.standard_cauchy(n)                                 # heavy tails / huge ranges
+    else:
+        x = rng.rand(n) * 1e-30                                    # tiny magnitudes (alpha < 1e-10 -> 1)
+    return x.astype(np.float32)
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=sizes, bucket=buckets, s=levels, seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 5),
+       clamp=st.sampled_from([False, False, 0.5, 2.0]))
+def test_uniform_matches_oracle(n, bucket, s, seed, kind, clamp):
+    x = make(n, seed, kind)
+    q, sf = quantization.uniformQuantization(torch.from_numpy(x).to(DEV), s, bucket_size=bucket, max_element=clamp)
+    r = oc.uniform_quantize(x, s, bucket, max_element=clamp)
+    assert np.array_equal(q.cpu().numpy(), r['q'])
+    assert np.array_equal(sf.alpha.cpu().numpy().reshape(-1), r['alpha'])
+    assert np.array_equal(sf.beta.cpu().numpy().reshape(-1), r['beta'])
+    assert np.array_equal(sf.idx_min_rows.cpu().numpy().reshape(-1), r['imin'])
+    assert np.array_equal(sf.idx_max_rows.cpu().numpy().reshape(-1), r['imax'])
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=sizes, bucket=buckets, k=st.sampled_from([1, 2, 3, 4, 5, 16, 17, 64, 200, 600]), seed=st.integers(0, 2 ** 31 - 1),
+       kind=st.integers(0, 3), dup=st.booleans())
+def test_nonuniform_matches_oracle(n, bucket, k, seed, kind, dup):
+    x = make(n, seed, kind)
+    rng = np.random.RandomState(seed ^ 0x5bd1)
+    pts = np.sort(rng.rand(k)).astype(np.float32)
+    if dup and k > 2:
+        pts[1] = pts[0]
+        pts[-1] = pts[-2]
+    xd, pd = torch.from_numpy(x).to(DEV), torch.from_numpy(pts).to(DEV)
+    q, idx, sf = quantization.nonUniformQuantization(xd, pd, bucket_size=bucket)
+    r = oc.nonuniform_quantize(x, pts, bucket, 'distance')
+    assert np.array_equal(idx.cpu().numpy(), r['idx']) and np.array_equal(q.cpu().numpy(), r['q'])
+    fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=xd)
+    qm = fn.forward(None, pd)
+    rm = oc.nonuniform_quantize(x, pts, bucket, 'midpoint')
+    assert np.array_equal(fn.savedForBackward['indices'].cpu().numpy(), rm['idx'])
+    assert np.array_equal(qm.cpu().numpy(), rm['q'])
+    g = rng.randn(n).astype(np.float32)
+    _, gp = fn.backward(torch.from_numpy(g).to(DEV))
+    want, absum = oc.point_grad(g, rm['idx'], rm['alpha'], bucket, k)
+    assert np.all(np.abs(gp.cpu().numpy().astype(np.float64) - want) <= 4e-6 * absum + 1e-30)
