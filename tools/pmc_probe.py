@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Runs each kernel of the path a few times at N = 16 Mi so that a rocprofv3 --pmc pass can attribute
+HBM traffic per kernel.  Writes gpurun_out/pmc_plan.json: for each label the kernel-name substring,
+which dispatches of that kernel belong to it, and the algorithmic bytes per launch."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import quantization  # noqa: E402
+from quantized_distillation_amd import _lib, codec  # noqa: E402
+
+N = 1 << 24
+REPS = 3
+dev = torch.device('cuda:0')
+# enough distinct buffers that nothing is served from the 256 MiB Infinity Cache by accident
+xs = [torch.randn(N, device=dev) for _ in range(6)]
+gs = [torch.randn(N, device=dev) for _ in range(6)]
+plan, counts = [], {}
+
+
+def record(label, kernel, algo_bytes, fn):
+    first = counts.get(kernel, 0)
+    for i in range(REPS):
+        fn(i)
+    counts[kernel] = first + REPS
+    plan.append(dict(label=label, kernel=kernel, first=first, reps=REPS, algorithmic_bytes=algo_bytes, n=N))
+
+
+keep = []
+record('K1 uniform 4-bit bucket 256', 'k_bucket_vec<0, 16, 4, 1>', 8 * N,
+       lambda i: keep.append(quantization.uniformQuantization(xs[i], 16, bucket_size=256)[0]))
+sf = quantization.ScalingFunction('linear', False, False, 256)
+record('K2 scale_down', 'k_bucket_vec<1, 16, 4, 1>', 8 * N, lambda i: keep.append(sf.scale_down(xs[i + 3])))
+u = sf.scale_down(xs[0])
+record('K3 inv_scale_down', 'k_inv_scale', 8 * N, lambda i: keep.append(sf.inv_scale_down(u)))
+pts = torch.tensor([0.0, 0.4, 0.6, 1.0], device=dev)
+record('K4 nonUniform k=4 int64 idx', 'k_bucket_vec<2, 16, 4, 1>', 16 * N,
+       lambda i: keep.append(quantization.nonUniformQuantization(xs[i], pts, bucket_size=256)[:2]))
+fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=xs[i]) for i in range(3)]
+# (preprocess ran K2 three more times)
+counts['k_bucket_vec<1, 16, 4, 1>'] = counts.get('k_bucket_vec<1, 16, 4, 1>', 0) + 4   # + sf.scale_down(xs[0]) above
+record('K5 diff-quant forward k=4 u8 idx', 'k_bucket_vec<2, 16, 4, 1>', 9 * N, lambda i: keep.append(fns[i].forward(None, pts)))
+record('K6 point gradient k=4 u8 idx', 'k_point_grad_fast<4, 1, true>', 5 * N, lambda i: keep.append(fns[i].backward(gs[i])[1]))
+fq = quantization.uniformQuantization_variable(16, bucket_size=256)
+
+
+def k7(i):
+    fq.saved_for_backward = {'input': xs[i + 3]}
+    keep.append(fq.backward(gs[i + 3]))
+
+
+record("K7 'complicated' STE backward", 'k_ste_backward_vec<16, 4>', 12 * N, k7)
+record('PK pack 4-bit', 'k_pack_vec<16, 4, 4>', int(4.5 * N), lambda i: keep.append(codec.pack_uniform(xs[i], 16, 256)))
+pk = codec.pack_uniform(xs[0], 16, 256)
+counts['k_pack_vec<16, 4, 4>'] += 1
+record('UPK unpack 4-bit', 'k_unpack<4>', int(4.5 * N), lambda i: keep.append(pk.unpack()))
+torch.cuda.synchronize()
+os.makedirs('gpurun_out', exist_ok=True)
+with open('gpurun_out/pmc_plan.json', 'w') as f:
+    json.dump(plan, f, indent=1)
+print('ok', len(plan))
