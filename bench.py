@@ -280,7 +280,7 @@ def diffquant_steps_per_sec(dev, steps=8, warmup=2, batch=100):
     from harness.distill import synthetic_batch
     torch.manual_seed(0)
     t0 = time.perf_counter()
-    tr = DiffQuantTrainer(models.WideResNet(16, 22), dev, num_points=4, bucket_size=256, lr=1e-5)
+    tr = DiffQuantTrainer(models.WideResNet(16, 22), dev, num_points=4, bucket_size=256, lr=1e-5, mode='multi')
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     x, y = synthetic_batch(batch, dev, seed=11)
@@ -301,9 +301,9 @@ def diffquant_steps_per_sec(dev, steps=8, warmup=2, batch=100):
             fn()
         torch.cuda.synchronize()
         phases[name] = round((time.perf_counter() - a) / reps * 1e3, 3)
-    timed('assign_all_tensors_ms (K5 x60)', tr.quantize)
+    timed('assign_all_tensors_ms (multi-tensor K5, 1 launch)', tr.quantize)
     timed('fwd_bwd_ms', lambda: tr.forward_backward(x, y))
-    timed('point_gradients_ms (K6 x60)', tr.point_gradients)
+    timed('point_gradients_ms (multi-tensor K6, 2 launches)', tr.point_gradients)
     nparams = sum(p.numel() for p in tr.params)
     return {'config': 'Wide_ResNet depth 16 widen 22 (60 tensors, %.1f M params), k=4 points (2-bit) per tensor, bucket 256, '
                       'percentile init, KD loss vs the unquantized model, SGD on the points; batch %d synthetic CIFAR10-shaped'

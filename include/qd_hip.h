@@ -150,6 +150,31 @@ int64_t qd_multi_plan(QdTensorDesc* host_table, int ntensors, int64_t bucket);
 int qd_multi_uniform_f32(const QdTensorDesc* table, int ntensors, int64_t total_tiles, int64_t bucket, int levels,
                          void* stream);
 
+/* ---- multi-tensor differentiable-quantization step: the per-tensor calls
+ *     p_quantized.data = quantizationFunctions[i].forward(None, points[i].data)   (conv_forward_model.py:532)
+ *     points[i].grad.data = quantizationFunctions[i].backward(p.grad.data)[1]     (conv_forward_model.py:545)
+ * for ALL tensors in one launch each.  Arithmetic = qd_nearest_point_f32(prescaled, MIDPOINT) with
+ * uint8 indices and qd_point_grad_f32.  k <= 64; bucket a power of two; `points` is one device
+ * array [ntensors][k] (so the optimizer updates a single tensor); grad_points likewise. */
+typedef struct QdDiffQuantDesc {
+    const float* u;       /* scaled weights, resident [n]                                  */
+    float* q;             /* quantized weights out [n]                                     */
+    uint8_t* idx;         /* point index out (forward) / in (backward) [n]                 */
+    const float* alpha;   /* [num_buckets]                                                 */
+    const float* beta;    /* [num_buckets]                                                 */
+    const float* grad;    /* dLoss/dq [n] (backward only)                                  */
+    int64_t n;
+    int64_t first_tile;   /* filled by qd_multi_dq_plan: prefix of 4-bucket tiles (forward) */
+    int64_t first_block;  /* filled by qd_multi_dq_plan: prefix of reduction blocks        */
+} QdDiffQuantDesc;
+/* Host helper: fills first_tile / first_block, returns total tiles, writes the total block count. */
+int64_t qd_multi_dq_plan(QdDiffQuantDesc* host_table, int ntensors, int64_t bucket, int64_t* total_blocks_out);
+int qd_multi_nearest_f32(const QdDiffQuantDesc* table, int ntensors, int64_t total_tiles, int64_t bucket,
+                         const float* points, int k, void* stream);
+/* workspace: at least total_blocks * k floats */
+int qd_multi_point_grad_f32(const QdDiffQuantDesc* table, int ntensors, int64_t total_blocks, int64_t bucket, int k,
+                            float* grad_points, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- packed-index codec (the compressed form whose SIZE the reference accounts for in
  * helpers/functions.py:226-262: bits*N/8 bytes of level indices + 8 bytes (alpha, beta) per
  * bucket) and the level histogram behind the Huffman accounting of

@@ -31,6 +31,13 @@ class QdTensorDesc(ctypes.Structure):
                 ('first_tile', ctypes.c_int64)]
 
 
+class QdDiffQuantDesc(ctypes.Structure):
+    """Mirror of `struct QdDiffQuantDesc` in include/qd_hip.h."""
+    _fields_ = [('u', ctypes.c_void_p), ('q', ctypes.c_void_p), ('idx', ctypes.c_void_p), ('alpha', ctypes.c_void_p),
+                ('beta', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('n', ctypes.c_int64),
+                ('first_tile', ctypes.c_int64), ('first_block', ctypes.c_int64)]
+
+
 # symbol -> (restype, argtypes); every symbol declared in include/qd_hip.h must be listed here
 # (tests/test_abi.py cross-checks this table against the header).
 SIGNATURES = {
@@ -54,6 +61,9 @@ SIGNATURES = {
     'qd_truncated_ste_f32': (c_int, [c_f, c_f, i64, c_float, c_p]),
     'qd_multi_plan': (i64, [ctypes.POINTER(QdTensorDesc), c_int, i64]),
     'qd_multi_uniform_f32': (c_int, [c_p, c_int, i64, i64, c_int, c_p]),
+    'qd_multi_dq_plan': (i64, [ctypes.POINTER(QdDiffQuantDesc), c_int, i64, ctypes.POINTER(ctypes.c_int64)]),
+    'qd_multi_nearest_f32': (c_int, [c_p, c_int, i64, i64, c_f, c_int, c_p]),
+    'qd_multi_point_grad_f32': (c_int, [c_p, c_int, i64, i64, c_int, c_f, c_p, c_size, c_p]),
     'qd_packed_bytes': (i64, [i64, c_int]),
     'qd_pack_uniform_f32': (c_int, [c_f, i64, i64, c_int, c_int, c_p, c_f, c_f, c_p]),
     'qd_unpack_uniform_f32': (c_int, [c_p, i64, i64, c_int, c_int, c_f, c_f, c_f, c_p]),

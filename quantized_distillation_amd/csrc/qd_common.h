@@ -147,7 +147,9 @@ __device__ __forceinline__ float qdq(float v, float a, float b, float sm1, float
     return y;
 }
 
-// ---- Philox4x32-10 counter-based generator for the stochastic-rounding branch ----
+// ---- Philox4x32-7 counter-based generator for the stochastic-rounding branch ----
+// 7 rounds is the smallest Philox4x32 variant that passes BigCrush (Salmon et al., SC'11); the
+// integer multiplies are quarter-rate on CDNA, so the rounds are what the stochastic kernel pays for.
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
@@ -161,7 +163,7 @@ __device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t block, f
     uint32_t c[4] = {(uint32_t)block, (uint32_t)(block >> 32), 0x51ed270bu, 0x2545f491u};
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < 7; ++r) {
         philox_round(c, k0, k1);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;

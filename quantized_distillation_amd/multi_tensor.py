@@ -72,3 +72,75 @@ class MultiTensorQuantizer(object):
             _lib.check(_lib.load().qd_multi_uniform_f32(self._table.data_ptr(), len(self.inputs), self._tiles,
                                                         self.bucket_size, self.s, _lib.stream_ptr()))
         return self.outputs
+
+
+class MultiTensorDiffQuant(object):
+    """Both per-step sweeps of differentiable quantization over ALL tensors of a model in one
+    launch each (qd_multi_nearest_f32 / qd_multi_point_grad_f32, include/qd_hip.h).
+
+    The reference loops over the tensors calling nonUniformQuantization_variable.forward and
+    .backward (cnn_models/conv_forward_model.py:524-545).  Here the scaled weights `u`, alpha and
+    beta of every tensor are computed once (K2) and stay resident; `points` is ONE [ntensors, k]
+    device tensor; every step
+        forward():  points -> quantized weights written straight into `outputs[i]` (+ uint8 indices)
+        backward(): gradients `grads[i]` -> grad of the points, [ntensors, k]
+    Results are bit-identical (forward) / equal to rounding (backward) to the per-tensor calls.
+    """
+
+    def __init__(self, tensors, outputs, grads, num_points, bucket_size):
+        from .quantization.quant_functions import ScalingFunction
+        if not isinstance(bucket_size, int) or bucket_size <= 0 or bucket_size & (bucket_size - 1):
+            raise ValueError('the multi-tensor diff-quant path needs a power-of-two bucket_size')
+        if not 1 <= num_points <= 64:
+            raise ValueError('the multi-tensor diff-quant path supports 1..64 points per tensor')
+        self.k, self.bucket_size = int(num_points), bucket_size
+        self.outputs, self.grads = list(outputs), list(grads)
+        self.device = tensors[0].device
+        self.scalings, self.scaled, self.indices = [], [], []
+        for t, o, g in zip(tensors, self.outputs, self.grads):
+            _lib.require_device_f32(t)
+            for other in (o, g):
+                _lib.require_device_f32(other)
+                if other.numel() != t.numel() or not other.is_contiguous():
+                    raise ValueError('outputs / grads must be contiguous and match the tensors in size')
+            sf = ScalingFunction('linear', False, False, bucket_size)
+            u = sf.scale_down(t).view(-1)[0:t.numel()].contiguous()
+            self.scalings.append(sf)
+            self.scaled.append(u)
+            self.indices.append(torch.empty(t.numel(), dtype=torch.uint8, device=self.device))
+        n = len(self.scaled)
+        lib = _lib.load()
+        host = (_lib.QdDiffQuantDesc * n)()
+        for i in range(n):
+            host[i].u = self.scaled[i].data_ptr()
+            host[i].q = self.outputs[i].data_ptr()
+            host[i].idx = self.indices[i].data_ptr()
+            host[i].alpha = self.scalings[i].alpha.data_ptr()
+            host[i].beta = self.scalings[i].beta.data_ptr()
+            host[i].grad = self.grads[i].data_ptr()
+            host[i].n = self.scaled[i].numel()
+        blocks = ctypes.c_int64(0)
+        self._tiles = int(lib.qd_multi_dq_plan(host, n, bucket_size, ctypes.byref(blocks)))
+        self._blocks = int(blocks.value)
+        if self._tiles < 0:
+            raise RuntimeError('qd_multi_dq_plan failed')
+        self._table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
+        self._scratch = torch.empty(max(1, self._blocks * self.k), dtype=torch.float32, device=self.device)
+        self.n_tensors = n
+
+    def forward(self, points):
+        """points: [ntensors, k] fp32 device tensor, each row sorted.  Writes outputs[i] in place."""
+        if points.shape != (self.n_tensors, self.k) or not points.is_contiguous():
+            raise ValueError('points must be a contiguous [ntensors, k] tensor')
+        _lib.check(_lib.load().qd_multi_nearest_f32(self._table.data_ptr(), self.n_tensors, self._tiles, self.bucket_size,
+                                                    points.data_ptr(), self.k, _lib.stream_ptr(self.device)))
+        return self.outputs
+
+    def backward(self, out=None):
+        """grad of the points from the gradient buffers given at construction: [ntensors, k]."""
+        if out is None:
+            out = torch.empty(self.n_tensors, self.k, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().qd_multi_point_grad_f32(self._table.data_ptr(), self.n_tensors, self._blocks,
+                                                       self.bucket_size, self.k, out.data_ptr(), self._scratch.data_ptr(),
+                                                       self._scratch.numel() * 4, _lib.stream_ptr(self.device)))
+        return out

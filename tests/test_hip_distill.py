@@ -112,3 +112,31 @@ def test_diffquant_step_against_oracle():
     for p, m in zip(tr.teacher.parameters(), masters):
         assert np.array_equal(p.detach().cpu().numpy(), m)
     assert torch.isfinite(tr.step(x, y))
+
+
+def test_multi_tensor_diffquant_equals_per_tensor():
+    """qd_multi_nearest_f32 / qd_multi_point_grad_f32 (one launch for all tensors) against the
+    per-tensor K5 / K6 calls: identical quantized weights and indices, point gradients equal to
+    rounding, and the same training trajectory."""
+    from harness.diffquant import DiffQuantTrainer
+    torch.manual_seed(0)
+    net = models.student()
+    a = DiffQuantTrainer(net, DEV, num_points=4, bucket_size=256, lr=1e-2, mode='per_tensor')
+    torch.manual_seed(0)
+    b = DiffQuantTrainer(models.student(), DEV, num_points=4, bucket_size=256, lr=1e-2, mode='multi')
+    assert torch.equal(a.points, b.points)
+    x, y = synthetic_batch(16, DEV, seed=5)
+    a.quantize(); b.quantize()
+    for pa, pb in zip(a.params, b.params):
+        assert torch.equal(pa.data, pb.data)
+    for row in range(len(a.slots)):
+        assert torch.equal(a.fns[row].savedForBackward.raw_indices().view(-1), b.mt.indices[row])
+    a.forward_backward(x, y); b.forward_backward(x, y)
+    a.point_gradients(); b.point_gradients()
+    scale = a.points_grad.abs().max()
+    assert torch.allclose(a.points_grad, b.points_grad, rtol=1e-4, atol=float(scale) * 1e-5)
+    for step in range(3):
+        xs, ys = synthetic_batch(16, DEV, seed=20 + step)
+        la, lb = a.step(xs, ys), b.step(xs, ys)
+        assert abs(float(la) - float(lb)) <= 1e-4 * max(1.0, abs(float(la)))
+    assert torch.allclose(a.points, b.points, rtol=1e-3, atol=1e-4)      # same trajectory up to fp32 summation order

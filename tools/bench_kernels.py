@@ -140,6 +140,14 @@ tot = sum(m.numel() for m in masters)
 mt = MultiTensorQuantizer(masters, 16, 256)
 timeit('K9  multi-tensor, %d tensors %.1f M params' % (len(masters), tot / 1e6), lambda i: mt.quantize(check_pointers=False), 8, n=tot)
 timeit('    same tensors, per-tensor API loop', lambda i: [quantization.uniformQuantization(m, 16, bucket_size=256) for m in masters], 8, n=tot, iters=10)
+from quantized_distillation_amd.multi_tensor import MultiTensorDiffQuant  # noqa: E402
+qs = [torch.empty_like(m) for m in masters]
+gr = [torch.randn_like(m) for m in masters]
+mdq = MultiTensorDiffQuant(masters, qs, gr, 4, 256)
+ptsm = torch.sort(torch.rand(len(masters), 4, device=dev), dim=1)[0].contiguous()
+timeit('K5m multi-tensor assign, %d tensors %.1f M, k=4' % (len(masters), tot / 1e6), lambda i: mdq.forward(ptsm), 9, n=tot)
+timeit('K6m multi-tensor point gradient, k=4', lambda i: mdq.backward(), 5, n=tot)
+del mdq, qs, gr
 from harness import models  # noqa: E402
 st = [p.data.to(dev) for p in models.student().parameters()]
 tot = sum(m.numel() for m in st)
