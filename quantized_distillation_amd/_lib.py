@@ -132,6 +132,13 @@ def workspace(device):
     return ws
 
 
+def on_other_device(t):
+    """True when `t` lives on a HIP device that is not the current one: kernels must be launched
+    with that device current (callers re-enter themselves under torch.cuda.device(t.device))."""
+    import torch
+    return t.is_cuda and t.device.index is not None and t.device.index != torch.cuda.current_device()
+
+
 def require_device_f32(t, what='tensor'):
     import torch
     if not isinstance(t, torch.Tensor):

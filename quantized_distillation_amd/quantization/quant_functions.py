@@ -183,6 +183,9 @@ class ScalingFunction(object):
         """u = (x - beta)/alpha per bucket, returned in the bucket layout (nb, bucket) -- padded
         with the scaled last element when the tensor is ragged -- or 1-D without buckets.
         ref: :56-129.  One kernel (K2)."""
+        if isinstance(tensor, torch.Tensor) and _lib.on_other_device(tensor):
+            with torch.cuda.device(tensor.device):
+                return self.scale_down(tensor)
         tensor, n, nb, row = self._begin(tensor)
         padded = nb * row
         in_place = self.modify_in_place and padded == n
@@ -199,6 +202,9 @@ class ScalingFunction(object):
 
     def inv_scale_down(self, tensor):
         """Inverse of scale_down (max_element truncation is not inverted).  ref: :131-152.  K3."""
+        if isinstance(tensor, torch.Tensor) and _lib.on_other_device(tensor):
+            with torch.cuda.device(tensor.device):
+                return self.inv_scale_down(tensor)
         _lib.require_device_f32(tensor)
         self._require_linear()
         if tensor.size() != self.expected_tensor_size:                               # ref: :138-139
@@ -223,6 +229,10 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     One fused kernel (K1) for bucketed tensors -- per-bucket min/max, alpha/beta, scale, round
     half to even, rescale; three small launches without buckets (global reduce, fold, apply).
     The input is left untouched unless modify_in_place=True."""
+    if isinstance(tensor, torch.Tensor) and _lib.on_other_device(tensor):
+        with torch.cuda.device(tensor.device):
+            return uniformQuantization(tensor, s, type_of_scaling, stochastic_rounding, max_element, subtract_mean,
+                                       bucket_size, modify_in_place)
     scaling_function = ScalingFunction(type_of_scaling, max_element, subtract_mean, bucket_size,
                                        modify_in_place=True)                         # as the reference, :166-167
     saved_flag = modify_in_place
@@ -328,6 +338,13 @@ def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
     gather, rescale).  Pre-processed path (`pre_processed_values=True`, the per-step call of
     differentiable quantization): the scaled tensor stays resident on the device inside
     `search_sorted_obj`, and one kernel (K5) assigns by the midpoint rule of :531-563."""
+    _where = tensor if isinstance(tensor, torch.Tensor) else (
+        search_sorted_obj.scaled_tensor if isinstance(search_sorted_obj, SearchSorted) else None)
+    if _where is not None and _lib.on_other_device(_where):
+        with torch.cuda.device(_where.device):
+            return nonUniformQuantization(tensor, listQuantizationPoints, max_element, subtract_mean, modify_in_place,
+                                          bucket_size, pre_processed_values, search_sorted_obj, scaling_function,
+                                          tensors_info)
     if pre_processed_values is True and (search_sorted_obj is None or scaling_function is None
                                          or tensors_info is None):                  # ref: :230-231
         raise ValueError('If values are preprocessed, all pre processed arguments need to be passed')
@@ -402,6 +419,9 @@ class uniformQuantization_variable(object):
             raise ValueError('Need to have called .forward() to be able to call .backward()')
         x = self.saved_for_backward['input']
         _lib.require_device_f32(grad_output, 'grad_output')
+        if _lib.on_other_device(grad_output):
+            with torch.cuda.device(grad_output.device):
+                return self.backward(grad_output, tie_mode)
         g = grad_output.contiguous()
         if g.numel() != x.numel():
             raise ValueError('grad_output must have as many elements as the input of forward()')
@@ -469,6 +489,9 @@ class nonUniformQuantization_variable(object):
         if listQuantizationPoints.dim() != 1:                                         # ref: :451-452
             raise ValueError('listPoints must be a 1-D tensor')
         numPoints = listQuantizationPoints.size()[0]
+        if self.pre_process_tensors and _lib.on_other_device(self.search_sorted_obj.scaled_tensor):
+            with torch.cuda.device(self.search_sorted_obj.scaled_tensor.device):
+                return self.forward(inputTensor, listQuantizationPoints)
         if self.pre_process_tensors:
             sf = self.scaling_function
             u = self.search_sorted_obj.scaled_tensor
@@ -492,6 +515,9 @@ class nonUniformQuantization_variable(object):
         if self.savedForBackward is None:                                             # ref: :478-479
             raise ValueError('Need savedIndices to be able to call backward()')
         _lib.require_device_f32(grad_output, 'grad_output')
+        if _lib.on_other_device(grad_output):
+            with torch.cuda.device(grad_output.device):
+                return self.backward(grad_output)
         idx = self.savedForBackward.raw_indices()
         k = self.savedForBackward['numPoints']
         alpha = self.savedForBackward['scalingFactor']

@@ -118,6 +118,43 @@ __global__ __launch_bounds__(256) void k_pg_probe(const float* g, const uint8_t*
     if ((threadIdx.x & 63) == 0)
         for (int j = 0; j < 4; ++j) part[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + j] = acc[j];
 }
+
+// ---- cache-policy probes: the same 256-element-bucket kernel with raw buffer loads/stores and an
+// explicit aux (cache policy) field: bit0 = sc0, bit1 = nt, bit4 = sc1 (guide: "aux 16 = sc1")
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int LA, int SA>
+__global__ __launch_bounds__(256) void k_qdq_buf(const float* x, float* q, int64_t nb, float sm1) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, l = lane & 15;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t bkt = wave * 4 + sub;
+    if (bkt >= nb) return;
+    // one resource per kernel: 256 MiB fits the 32-bit num_records
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(nb * 1024), 0x00020000);
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, (int)(nb * 1024), 0x00020000);
+    const int off = (int)(bkt * 1024 + l * 16);
+    f4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v4i t = __builtin_amdgcn_raw_buffer_load_b128(rx, off + j * 256, 0, LA);
+        v[j] = __builtin_bit_cast(f4, t);
+    }
+    float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
+    float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
+        mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+    }
+    mn = row16_min(mn); mx = row16_max(mx);
+    float a, b, lev; alpha_beta(mn, mx, a, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f4 r;
+        r.x = qdq(v[j].x, a, b, sm1, 0.f, lev); r.y = qdq(v[j].y, a, b, sm1, 0.f, lev);
+        r.z = qdq(v[j].z, a, b, sm1, 0.f, lev); r.w = qdq(v[j].w, a, b, sm1, 0.f, lev);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, r), rq, off + j * 256, 0, SA);
+    }
+}
 struct Variant { std::string name; std::function<void(int)> run; std::vector<float> us; };
 
 int main(int argc, char** argv) {
@@ -174,7 +211,24 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st0, (const float*)x[i & 3], (const uint8_t*)idx8[i & 3], (const float*)alph, N, part);
         }, {}});
     };
-    if (argc > 3 && std::string(argv[3]) == "pg") {
+    if (argc > 3 && std::string(argv[3]) == "aux") {
+        const int64_t blocks16 = nb / 16;
+        auto addb = [&](const char* nm, auto kern) {
+            vs.push_back({nm, [=](int i) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks16), dim3(256), 0, st0, (const float*)x[i & 3], y[i & 3], nb, 15.0f); }, {}});
+        };
+        addq("qdq nt (global_load/store nt) reference", k_qdq<true, 16, 4, 0>, 256, nb / 4, 0);
+        addb("buf ld nt(2)   st nt(2)", k_qdq_buf<2, 2>);
+        addb("buf ld nt(2)   st sc1(16)", k_qdq_buf<2, 16>);
+        addb("buf ld nt(2)   st sc1+nt(18)", k_qdq_buf<2, 18>);
+        addb("buf ld nt(2)   st sc0+sc1(17)", k_qdq_buf<2, 17>);
+        addb("buf ld nt(2)   st all(19)", k_qdq_buf<2, 19>);
+        addb("buf ld plain   st nt(2)", k_qdq_buf<0, 2>);
+        addb("buf ld sc1(16) st nt(2)", k_qdq_buf<16, 2>);
+        addb("buf ld sc1+nt  st nt(2)", k_qdq_buf<18, 2>);
+        addb("buf ld sc0(1)  st nt(2)", k_qdq_buf<1, 2>);
+        addb("buf ld sc1+nt  st sc1+nt", k_qdq_buf<18, 18>);
+        addb("buf ld plain   st plain", k_qdq_buf<0, 0>);
+    } else if (argc > 3 && std::string(argv[3]) == "pg") {
         addp("pg L0 read g only, unr1, 8192 blk", k_pg_probe<0, 1>, 8192);
         addp("pg L0 read g only, unr2, 8192 blk", k_pg_probe<0, 2>, 8192);
         addp("pg L0 read g only, unr4, 8192 blk", k_pg_probe<0, 4>, 8192);
