@@ -150,6 +150,22 @@ int64_t qd_multi_plan(QdTensorDesc* host_table, int ntensors, int64_t bucket);
 int qd_multi_uniform_f32(const QdTensorDesc* table, int ntensors, int64_t total_tiles, int64_t bucket, int levels,
                          void* stream);
 
+/* ---- 'absmax' / 'absnorm' scaling (type_scaling of ScalingFunction, quant_functions.py:109-127,144-146).
+ * PARITY UNPINNED: the reference code for these two types raises on every torch version, so these
+ * entry points implement the math those lines evidently intend (see qd_abs.hip):
+ *     sign = sign(x), m = |x|, norm_b = max_b m (norm_kind 0) or sqrt(sum_b m^2) (norm_kind 1), < 1e-10 -> 1
+ *     qd_scale_down_abs_f32 : u = m/norm_b and sign, both in the PADDED bucket layout; norm_out [num_buckets]
+ *     qd_inv_scale_abs_f32  : y = u*norm_b*sign (+mean), padding dropped
+ *     qd_uniform_abs_f32    : q = rint(u*(levels-1))/(levels-1)*norm_b*sign (+mean) */
+int qd_uniform_abs_f32(const float* x, float* q, int64_t n, int64_t bucket, int levels, int norm_kind, float* norm_out,
+                       const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int qd_scale_down_abs_f32(const float* x, float* u, float* sign, int64_t n, int64_t bucket, int norm_kind,
+                          float* norm_out, const float* mean, int clamp, float max_element, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int qd_inv_scale_abs_f32(const float* u, const float* sign, float* y, int64_t n, int64_t bucket, const float* norm,
+                         const float* mean, void* stream);
+
 /* ---- multi-tensor differentiable-quantization step: the per-tensor calls
  *     p_quantized.data = quantizationFunctions[i].forward(None, points[i].data)   (conv_forward_model.py:532)
  *     points[i].grad.data = quantizationFunctions[i].backward(p.grad.data)[1]     (conv_forward_model.py:545)

@@ -248,3 +248,43 @@ def init_points_percentile(x, bucket, k, max_element=False, subtract_mean=False)
     sd = scale_down(x, bucket, max_element, subtract_mean)
     flat = sd['u'].reshape(-1)[:sd['n']]
     return np.percentile(flat, np.linspace(0, 100, num=k)).astype(F32)
+
+
+# ----------------------------------------------------------------------------- absmax / absnorm
+# PARITY UNPINNED: the reference's code for these scaling types (quant_functions.py:109-127,144-146)
+# raises on every torch version, so there is nothing to pin against.  This restates the math
+# those lines evidently intend; it only checks that the HIP kernels do what DESIGN.md says.
+def scale_down_abs(x, bucket=None, kind='absmax', norm=None):
+    """sign, u = |x| / norm_b with norm_b = max|x| ('absmax') or sqrt(sum x^2) ('absnorm') per bucket,
+    norm < 1e-10 -> 1.  `norm` overrides the per-bucket norms (fp32 summation order of the L2 norm
+    is implementation specific).  Returns dict(u, sign, norm) in the padded bucket layout."""
+    x = np.asarray(x, dtype=F32)
+    v = x.reshape(-1)
+    n = v.size
+    t = bucketize(v, bucket)
+    t2 = t.reshape(1, -1) if bucket is None else t
+    sign = np.sign(t2).astype(F32)
+    m = np.abs(t2)
+    if norm is None:
+        if kind == 'absmax':
+            nrm = m.max(axis=1, keepdims=True).astype(F32)
+        else:
+            nrm = np.sqrt((m.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(F32)
+        nrm = np.where(nrm < F32(TOL_DIFF_ZERO), F32(1.0), nrm).astype(F32)
+    else:
+        nrm = np.asarray(norm, dtype=F32).reshape(-1, 1)
+    u = (m / nrm).astype(F32)
+    return dict(u=u.reshape(t.shape), sign=sign.reshape(t.shape), norm=nrm.reshape(-1), n=n, shape=x.shape)
+
+
+def uniform_quantize_abs(x, s, bucket=None, kind='absmax', norm=None):
+    sd = scale_down_abs(x, bucket, kind, norm)
+    sm1 = F32(s - 1)
+    u2 = sd['u'].reshape(sd['norm'].size, -1)
+    w = (np.rint((u2 * sm1).astype(F32)).astype(F32) / sm1).astype(F32)
+    y = (w * sd['norm'].reshape(-1, 1)).astype(F32)
+    y = (y * sd['sign'].reshape(u2.shape)).astype(F32)
+    y = (y + F32(0.0)).astype(F32)
+    out = dict(sd)
+    out['q'] = y.reshape(-1)[:sd['n']].reshape(sd['shape'])
+    return out

@@ -81,14 +81,12 @@ class ScalingFunction(object):
         self._mean_buf = None
 
     # ------------------------------------------------------------------ helpers
-    def _require_linear(self):
-        if self.type_scaling != 'linear':
-            # ref: :109-127 raises on every torch version (tensor.max(p=2, ...) is not a valid call
-            # and :126 stores a bound method), so there is no behaviour to be compatible with.
-            raise NotImplementedError(
-                "type_scaling '%s' is not available: the reference implementation of absmax/absnorm "
-                "(quant_functions.py:109-127) raises on every torch version; only 'linear' is defined"
-                % self.type_scaling)
+    def _abs_kind(self):
+        """None for linear scaling; 0 ('absmax': max|x| per bucket) or 1 ('absnorm': L2 norm per bucket).
+        The reference's code for the two abs types raises on every torch version
+        (ref: :109-127 -- `tensor.max(p=2, ...)` is not a valid call, :126 stores a bound method), so these
+        follow the intended math only (parity unpinned; see csrc/qd_abs.hip)."""
+        return {'linear': None, 'absmax': 0, 'absnorm': 1}[self.type_scaling]
 
     def _clamp_args(self):
         if self.max_element is False:
@@ -98,7 +96,6 @@ class ScalingFunction(object):
     def _begin(self, tensor):
         """Record sizes, compute the mean if requested; returns (flat contiguous tensor, n, nb, row)."""
         _lib.require_device_f32(tensor)
-        self._require_linear()
         if not tensor.is_contiguous():
             if self.modify_in_place:
                 raise ValueError('modify_in_place=True needs a contiguous tensor')
@@ -188,6 +185,8 @@ class ScalingFunction(object):
                 return self.scale_down(tensor)
         tensor, n, nb, row = self._begin(tensor)
         padded = nb * row
+        if self._abs_kind() is not None:
+            return self._scale_down_abs(tensor, n, nb, padded)
         in_place = self.modify_in_place and padded == n
         self._note_arg_source(tensor, overwritten=in_place)
         out = tensor.view(-1) if in_place else torch.empty(padded, dtype=torch.float32, device=tensor.device)
@@ -200,18 +199,42 @@ class ScalingFunction(object):
                 ab[1].data_ptr(), _ptr(self._mean_buf), clamp, me, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         return out.view(self.expected_tensor_size)
 
+    def _scale_down_abs(self, tensor, n, nb, padded):
+        """sign + magnitude scaling (intended math of ref: :109-127): u = |x| / norm_b."""
+        dev = tensor.device
+        u = torch.empty(padded, dtype=torch.float32, device=dev)
+        sign = torch.empty(padded, dtype=torch.float32, device=dev)
+        norm = torch.empty(nb, dtype=torch.float32, device=dev)
+        clamp, me = self._clamp_args()
+        if n > 0:
+            ws = _lib.workspace(dev)
+            _lib.check(_lib.load().qd_scale_down_abs_f32(
+                tensor.data_ptr(), u.data_ptr(), sign.data_ptr(), n, _bucket_arg(self.bucket_size), self._abs_kind(),
+                norm.data_ptr(), _ptr(self._mean_buf), clamp, me, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+        self.norm_scaling = norm.view(1) if self.bucket_size is None else norm.view(nb, 1)
+        self.tensor_sign = sign.view(self.expected_tensor_size)
+        return u.view(self.expected_tensor_size)
+
     def inv_scale_down(self, tensor):
         """Inverse of scale_down (max_element truncation is not inverted).  ref: :131-152.  K3."""
         if isinstance(tensor, torch.Tensor) and _lib.on_other_device(tensor):
             with torch.cuda.device(tensor.device):
                 return self.inv_scale_down(tensor)
         _lib.require_device_f32(tensor)
-        self._require_linear()
         if tensor.size() != self.expected_tensor_size:                               # ref: :138-139
             raise ValueError('The tensor passed has not the expected size.')
         if not tensor.is_contiguous():
             tensor = tensor.contiguous()
         n = self.original_tensor_length
+        if self._abs_kind() is not None:                                             # ref: :144-146
+            if self.tensor_sign is None:
+                raise ValueError('inv_scale_down needs the signs recorded by scale_down')
+            out = torch.empty(n, dtype=torch.float32, device=tensor.device)
+            if n > 0:
+                _lib.check(_lib.load().qd_inv_scale_abs_f32(
+                    tensor.data_ptr(), self.tensor_sign.data_ptr(), out.data_ptr(), n, _bucket_arg(self.bucket_size),
+                    self.norm_scaling.data_ptr(), _ptr(self._mean_buf), _lib.stream_ptr(tensor.device)))
+            return out.view(self.original_tensor_size)
         out = tensor.view(-1)[0:n] if self.modify_in_place else torch.empty(n, dtype=torch.float32,
                                                                           device=tensor.device)
         if n > 0:
@@ -241,6 +264,20 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     scaling_function.modify_in_place = True
     if int(s) != s or s < 2:
         raise ValueError('s must be an integer >= 2')
+    if scaling_function._abs_kind() is not None:
+        if stochastic_rounding:
+            raise NotImplementedError('stochastic rounding is implemented for linear scaling only')
+        out = tensor if modify_in_place else torch.empty_like(tensor)
+        norm = torch.empty(nb, dtype=torch.float32, device=tensor.device)
+        clamp, me = scaling_function._clamp_args()
+        if n > 0:
+            ws = _lib.workspace(tensor.device)
+            _lib.check(_lib.load().qd_uniform_abs_f32(
+                tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), scaling_function._abs_kind(),
+                norm.data_ptr(), _ptr(scaling_function._mean_buf), clamp, me, ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(tensor.device)))
+        scaling_function.norm_scaling = norm.view(1) if bucket_size is None else norm.view(nb, 1)
+        return out, scaling_function
     scaling_function._note_arg_source(tensor, overwritten=saved_flag)
     out = tensor if modify_in_place else torch.empty_like(tensor)
     ab = scaling_function._alloc_alpha_beta(nb, tensor.device)

@@ -478,3 +478,34 @@ def test_level_histogram_and_device_huffman(golden_misc):
         if c['kind'] == 'uniform':
             got = codec.huffman_mean_bit_length_uniform(params, c['s'], c['bucket'])
             assert abs(got - c['mean_bit_length']) < 1e-12, (c, got)
+
+
+# ------------------------------------------------------------------------------ absmax / absnorm (parity unpinned)
+@pytest.mark.parametrize('kind', ['absmax', 'absnorm'])
+def test_abs_scaling_intended_math(kind):
+    """The reference raises for these scaling types on every torch version, so this only checks the
+    kernels against the oracle's restatement of the intended math (parity unpinned)."""
+    rng = np.random.RandomState(5)
+    for n, bucket in [(1000, 256), (5000, None), (257, 256), (100003, 256), (300000, None), (64, 100)]:
+        x = rng.randn(n).astype(np.float32)
+        x[::97] = 0.0
+        xd = dev(x)
+        sf = quantization.ScalingFunction(kind, False, False, bucket)
+        u = sf.scale_down(xd)
+        ref = onp.scale_down_abs(x, bucket, kind)
+        nrm = host(sf.norm_scaling).reshape(-1)
+        if kind == 'absmax':
+            assert np.array_equal(nrm, ref['norm'])
+        else:
+            assert np.allclose(nrm, ref['norm'], rtol=2e-6, atol=0)
+        ref = onp.scale_down_abs(x, bucket, kind, norm=nrm)          # exact given the device's norms
+        assert np.array_equal(host(u), ref['u'].reshape(host(u).shape))
+        assert np.array_equal(host(sf.tensor_sign), ref['sign'].reshape(host(u).shape))
+        back = host(sf.inv_scale_down(u))
+        assert np.allclose(back, x, rtol=3e-7, atol=1e-30) and back.shape == x.shape
+        q, sf2 = quantization.uniformQuantization(xd, 8, type_of_scaling=kind, bucket_size=bucket)
+        nrm2 = host(sf2.norm_scaling).reshape(-1)
+        assert np.array_equal(host(q), onp.uniform_quantize_abs(x, 8, bucket, kind, norm=nrm2)['q'])
+        assert np.all(host(q)[x == 0] == 0)
+    with pytest.raises(ValueError):
+        quantization.uniformQuantization_variable(16, type_of_scaling=kind, bucket_size=256).backward(dev(x))
