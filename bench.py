@@ -52,8 +52,9 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(x_host):
-    """The reference's algorithm on the host cores, same workload, bounded sample."""
+def cpu_baseline(x_host, q_gpu, alpha_gpu):
+    """The reference's algorithm on the host cores, same workload, bounded sample; the oracle's
+    output doubles as the checker of the GPU result for the same tensor (q_gpu, alpha_gpu)."""
     import numpy as np
     from oracle import oracle_c
     from oracle.torch_port import uniform_quantize_torch_ops
@@ -61,7 +62,9 @@ def cpu_baseline(x_host):
     cores = oracle_c.max_threads()
     xn = x_host.numpy()
     n = xn.size
-    oracle_c.uniform_quantize(xn, LEVELS, BUCKET, want_idx=False, want_lev=False)       # warm-up
+    ref = oracle_c.uniform_quantize(xn, LEVELS, BUCKET, want_idx=False, want_lev=False)       # warm-up + checker
+    bit_exact = bool(np.array_equal(q_gpu, ref['q']) and np.array_equal(alpha_gpu, ref['alpha']))
+    del ref
     times = []
     t_end = time.time() + 12.0
     while len(times) < 10 and (time.time() < t_end or len(times) < 3):
@@ -74,7 +77,7 @@ def cpu_baseline(x_host):
         'sample': '%d runs of the full workload (N=%d fp32, s=%d, bucket=%d); C port of the reference '
                   'algorithm (oracle/qd_oracle.c, OpenMP over buckets); min %.4f s, median %.4f s'
                   % (len(times), n, LEVELS, BUCKET, best, med),
-        'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(),
+        'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(), 'gpu_result_bit_exact': bit_exact,
     }
     # the reference's own op chain (multi-threaded torch CPU ops), restated in oracle/torch_port.py
     torch.set_num_threads(min(os.cpu_count() or 1, 64))     # 256 SMT threads oversubscribe torch's elementwise ops
@@ -416,19 +419,15 @@ def main():
     torch.cuda.synchronize()
     copy_gbps = ALGO_BYTES_PER_ELEM * N_ELEM * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
-    # parity spot check in the same run (rank 0): bit-exact against the CPU oracle
+    # cpu_baseline leg (rank 0, N=1 only): the oracle is timed on the host cores and, in the same leg,
+    # used as the checker of the GPU result computed above (bit-exact comparison)
     parity = None
     cpu = None
-    if rank == 0:
-        import numpy as np
-        from oracle import oracle_c
-        oracle_c.build()
-        ref = oracle_c.uniform_quantize(x_host.numpy(), LEVELS, BUCKET, want_idx=False, want_lev=False)
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         q, sf = quantization.uniformQuantization(xs[0], LEVELS, bucket_size=BUCKET)
-        parity = bool(np.array_equal(q.cpu().numpy(), ref['q']) and
-                      np.array_equal(sf.alpha.cpu().numpy().reshape(-1), ref['alpha']))
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(x_host)
+        cpu = cpu_baseline(x_host, q.cpu().numpy(), sf.alpha.cpu().numpy().reshape(-1))
+        parity = cpu.pop('gpu_result_bit_exact')
+        del q, sf
 
     distill = None
     if not args.no_distill:
