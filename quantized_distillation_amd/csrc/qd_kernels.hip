@@ -278,64 +278,143 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t ntiles = (p.nvec + BPW - 1) / BPW;
 
-    for (int64_t t = wave; t < ntiles; t += nwaves) {
-        const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
-        f4 v[U][V];
-        float a_keep = 0.0f, b_keep = 0.0f;
-#pragma unroll
-        for (int uu = 0; uu < U; ++uu) {
-            if (bkt0 + uu < p.nvec) {
-                const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
-#pragma unroll
-                for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
+    // Two code shapes, chosen at compile time by what the compiler turns into the fewest VALU
+    // instructions (SQ_INSTS_VALU, profiles/r01_sq_counters.txt): with one bucket per lane group the
+    // straight-line loop is best (bucket 256: 44.9 M vs 60.3 M wave-instructions); with several
+    // buckets per group the unpredicated whole-tile path is (bucket 64: 52.9 M vs 74.6 M).
+    if constexpr (U == 1) {
+        for (int64_t t = wave; t < ntiles; t += nwaves) {
+            const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
+            f4 v[U][V];
+            float a_keep = 0.0f, b_keep = 0.0f;
+    #pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                if (bkt0 + uu < p.nvec) {
+                    const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
+    #pragma unroll
+                    for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
+                }
             }
-        }
-#pragma unroll
-        for (int uu = 0; uu < U; ++uu) {
-            const int64_t bkt = bkt0 + uu;
-            if (bkt < p.nvec) {
-                const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
-                float a, b;
-                if (prescaled) {
-                    a = p.alpha[bkt]; b = p.beta[bkt];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
-                    float mn = fminf(fminf(v[uu][0].x, v[uu][0].y), fminf(v[uu][0].z, v[uu][0].w));
-                    float mx = fmaxf(fmaxf(v[uu][0].x, v[uu][0].y), fmaxf(v[uu][0].z, v[uu][0].w));
-#pragma unroll
-                    for (int j = 1; j < V; ++j) {
-                        mn = fminf(mn, fminf(fminf(v[uu][j].x, v[uu][j].y), fminf(v[uu][j].z, v[uu][j].w)));
-                        mx = fmaxf(mx, fmaxf(fmaxf(v[uu][j].x, v[uu][j].y), fmaxf(v[uu][j].z, v[uu][j].w)));
+    #pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                const int64_t bkt = bkt0 + uu;
+                if (bkt < p.nvec) {
+                    const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
+                    float a, b;
+                    if (prescaled) {
+                        a = p.alpha[bkt]; b = p.beta[bkt];
+                    } else {
+    #pragma unroll
+                        for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
+                        float mn = fminf(fminf(v[uu][0].x, v[uu][0].y), fminf(v[uu][0].z, v[uu][0].w));
+                        float mx = fmaxf(fmaxf(v[uu][0].x, v[uu][0].y), fmaxf(v[uu][0].z, v[uu][0].w));
+    #pragma unroll
+                        for (int j = 1; j < V; ++j) {
+                            mn = fminf(mn, fminf(fminf(v[uu][j].x, v[uu][j].y), fminf(v[uu][j].z, v[uu][j].w)));
+                            mx = fmaxf(mx, fmaxf(fmaxf(v[uu][j].x, v[uu][j].y), fmaxf(v[uu][j].z, v[uu][j].w)));
+                        }
+                        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
+                        else { mn = wave_min(mn); mx = wave_max(mx); }
+                        alpha_beta(mn, mx, a, b);
+                        if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
                     }
-                    if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
-                    else { mn = wave_min(mn); mx = wave_max(mx); }
-                    alpha_beta(mn, mx, a, b);
-                    if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
-                }
-                f4* dst = (f4*)(p.out + e0);
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    const int64_t e = e0 + (int64_t)j * LPB * 4;
-                    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
-                    float side[4];
-                    f4 r;
-                    r.x = transform<MODE>(p, T, v[uu][j].x, a, b, pp.mean, rnd[0], side[0]);
-                    r.y = transform<MODE>(p, T, v[uu][j].y, a, b, pp.mean, rnd[1], side[1]);
-                    r.z = transform<MODE>(p, T, v[uu][j].z, a, b, pp.mean, rnd[2], side[2]);
-                    r.w = transform<MODE>(p, T, v[uu][j].w, a, b, pp.mean, rnd[3], side[3]);
-                    __builtin_nontemporal_store(r, dst + j * LPB);
-                    store_side4<MODE>(p, e, side);
+                    f4* dst = (f4*)(p.out + e0);
+    #pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const int64_t e = e0 + (int64_t)j * LPB * 4;
+                        float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                        float side[4];
+                        f4 r;
+                        r.x = transform<MODE>(p, T, v[uu][j].x, a, b, pp.mean, rnd[0], side[0]);
+                        r.y = transform<MODE>(p, T, v[uu][j].y, a, b, pp.mean, rnd[1], side[1]);
+                        r.z = transform<MODE>(p, T, v[uu][j].z, a, b, pp.mean, rnd[2], side[2]);
+                        r.w = transform<MODE>(p, T, v[uu][j].w, a, b, pp.mean, rnd[3], side[3]);
+                        __builtin_nontemporal_store(r, dst + j * LPB);
+                        store_side4<MODE>(p, e, side);
+                    }
                 }
             }
+            // alpha/beta of the group's U buckets: lanes 0..U-1 write U consecutive floats (one store
+            // instruction per array per tile instead of U single-lane stores)
+            if (!prescaled && l < U && bkt0 + l < p.nvec) {
+                if (p.alpha) p.alpha[bkt0 + l] = a_keep;
+                if (p.beta) p.beta[bkt0 + l] = b_keep;
+            }
         }
-        // alpha/beta of the group's U buckets: lanes 0..U-1 write U consecutive floats (one store
-        // instruction per array per tile instead of U single-lane stores)
-        if (!prescaled && l < U && bkt0 + l < p.nvec) {
-            if (p.alpha) p.alpha[bkt0 + l] = a_keep;
-            if (p.beta) p.beta[bkt0 + l] = b_keep;
+
+    } else {
+        // one bucket: v[0..V) are already loaded; reduce, transform, store
+        auto process = [&](f4 (&v)[V], int64_t bkt, int uu, float& a_keep, float& b_keep) {
+            const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
+            float a, b;
+            if (prescaled) {
+                a = p.alpha[bkt]; b = p.beta[bkt];
+            } else {
+    #pragma unroll
+                for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
+                float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
+                float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+    #pragma unroll
+                for (int j = 1; j < V; ++j) {
+                    mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
+                    mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+                }
+                if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
+                else { mn = wave_min(mn); mx = wave_max(mx); }
+                alpha_beta(mn, mx, a, b);
+                if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
+            }
+            f4* dst = (f4*)(p.out + e0);
+    #pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int64_t e = e0 + (int64_t)j * LPB * 4;
+                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                float side[4];
+                f4 r;
+                r.x = transform<MODE>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0]);
+                r.y = transform<MODE>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1]);
+                r.z = transform<MODE>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2]);
+                r.w = transform<MODE>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3]);
+                __builtin_nontemporal_store(r, dst + j * LPB);
+                store_side4<MODE>(p, e, side);
+            }
+        };
+
+        for (int64_t t = wave; t < ntiles; t += nwaves) {
+            const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
+            float a_keep = 0.0f, b_keep = 0.0f;
+            if (bkt0 + U <= p.nvec) {
+                // whole group in range (every tile but possibly the last): unpredicated, all loads first
+                f4 v[U][V];
+    #pragma unroll
+                for (int uu = 0; uu < U; ++uu) {
+                    const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
+    #pragma unroll
+                    for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
+                }
+    #pragma unroll
+                for (int uu = 0; uu < U; ++uu) process(v[uu], bkt0 + uu, uu, a_keep, b_keep);
+            } else {
+                for (int uu = 0; uu < U; ++uu) {
+                    if (bkt0 + uu < p.nvec) {
+                        f4 v[V];
+                        const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
+    #pragma unroll
+                        for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * LPB);
+                        process(v, bkt0 + uu, uu, a_keep, b_keep);
+                    }
+                }
+            }
+            // alpha/beta of the group's U buckets: lanes 0..U-1 write U consecutive floats (one store
+            // instruction per array per tile instead of U single-lane stores)
+            if (!prescaled && l < U && bkt0 + l < p.nvec) {
+                if (p.alpha) p.alpha[bkt0 + l] = a_keep;
+                if (p.beta) p.beta[bkt0 + l] = b_keep;
+            }
         }
+
     }
 
     // buckets after the vector part (the ragged last bucket): one DPP row each, last block
