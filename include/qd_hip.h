@@ -150,6 +150,14 @@ int64_t qd_multi_plan(QdTensorDesc* host_table, int ntensors, int64_t bucket);
 int qd_multi_uniform_f32(const QdTensorDesc* table, int ntensors, int64_t total_tiles, int64_t bucket, int levels,
                          void* stream);
 
+/* Multi-tensor K1g: the same per-step loop with bucket_size=None (every tensor one bucket with its
+ * own global min/max; e.g. cifar10_test.py:113): three launches for the whole model (per-tile
+ * min/max, per-tensor fold, apply) instead of three per tensor.  qd_multi_global_plan fills
+ * first_tile (1024-element tiles); alpha_beta: [ntensors][2] output; workspace >= total_tiles*8 bytes. */
+int64_t qd_multi_global_plan(QdTensorDesc* host_table, int ntensors);
+int qd_multi_uniform_global_f32(const QdTensorDesc* table, int ntensors, int64_t total_tiles, int levels,
+                                float* alpha_beta, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- 'absmax' / 'absnorm' scaling (type_scaling of ScalingFunction, quant_functions.py:109-127,144-146).
  * PARITY UNPINNED: the reference code for these two types raises on every torch version, so these
  * entry points implement the math those lines evidently intend (see qd_abs.hip):

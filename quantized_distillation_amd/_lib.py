@@ -61,6 +61,8 @@ SIGNATURES = {
     'qd_truncated_ste_f32': (c_int, [c_f, c_f, i64, c_float, c_p]),
     'qd_multi_plan': (i64, [ctypes.POINTER(QdTensorDesc), c_int, i64]),
     'qd_multi_uniform_f32': (c_int, [c_p, c_int, i64, i64, c_int, c_p]),
+    'qd_multi_global_plan': (i64, [ctypes.POINTER(QdTensorDesc), c_int]),
+    'qd_multi_uniform_global_f32': (c_int, [c_p, c_int, i64, c_int, c_f, c_p, c_size, c_p]),
     'qd_uniform_abs_f32': (c_int, [c_f, c_f, i64, i64, c_int, c_int, c_f, c_f, c_int, c_float, c_p, c_size, c_p]),
     'qd_scale_down_abs_f32': (c_int, [c_f, c_f, c_f, i64, i64, c_int, c_f, c_f, c_int, c_float, c_p, c_size, c_p]),
     'qd_inv_scale_abs_f32': (c_int, [c_f, c_f, c_f, i64, i64, c_f, c_f, c_p]),

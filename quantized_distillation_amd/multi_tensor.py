@@ -20,8 +20,8 @@ from . import _lib
 
 class MultiTensorQuantizer(object):
     def __init__(self, tensors, s, bucket_size, outputs=None):
-        if bucket_size is None or not isinstance(bucket_size, int) or bucket_size <= 0:
-            raise ValueError('the multi-tensor path needs a positive integer bucket_size')
+        if bucket_size is not None and (not isinstance(bucket_size, int) or bucket_size <= 0):
+            raise ValueError('bucket_size must be a positive integer or None')
         if int(s) != s or s < 2:
             raise ValueError('s must be an integer >= 2')
         self.s = int(s)
@@ -54,7 +54,12 @@ class MultiTensorQuantizer(object):
             host[i].x = t.data_ptr()
             host[i].q = o.data_ptr()
             host[i].n = t.numel()
-        self._tiles = int(lib.qd_multi_plan(host, n, self.bucket_size))
+        if self.bucket_size is None:
+            self._tiles = int(lib.qd_multi_global_plan(host, n))
+            self.alpha_beta = torch.empty(n, 2, dtype=torch.float32, device=self.device)     # per-tensor (alpha, beta)
+            self._scratch = torch.empty(max(4, 2 * self._tiles), dtype=torch.float32, device=self.device)
+        else:
+            self._tiles = int(lib.qd_multi_plan(host, n, self.bucket_size))
         if self._tiles < 0:
             raise RuntimeError('qd_multi_plan failed')
         raw = bytes(host)
@@ -68,9 +73,13 @@ class MultiTensorQuantizer(object):
                 if t.data_ptr() != px or o.data_ptr() != pq:
                     self._plan()       # storage moved (e.g. p.data was rebound): rebuild the table
                     break
-        if self._tiles > 0:
+        if self._tiles > 0 and self.bucket_size is None:
+            _lib.check(_lib.load().qd_multi_uniform_global_f32(
+                self._table.data_ptr(), len(self.inputs), self._tiles, self.s, self.alpha_beta.data_ptr(),
+                self._scratch.data_ptr(), self._scratch.numel() * 4, _lib.stream_ptr(self.device)))
+        elif self._tiles > 0:
             _lib.check(_lib.load().qd_multi_uniform_f32(self._table.data_ptr(), len(self.inputs), self._tiles,
-                                                        self.bucket_size, self.s, _lib.stream_ptr()))
+                                                        self.bucket_size, self.s, _lib.stream_ptr(self.device)))
         return self.outputs
 
 

@@ -13,15 +13,16 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
 
 
-def make(mode, first_last=True, style='none'):
+def make(mode, first_last=True, style='none', bucket=256):
     torch.manual_seed(0)
     st, te = models.student(), models.teacher()
-    return DistillTrainer(st, te, DEV, num_bits=4, bucket_size=256, mode=mode, quantize_first_and_last_layer=first_last,
+    return DistillTrainer(st, te, DEV, num_bits=4, bucket_size=bucket, mode=mode, quantize_first_and_last_layer=first_last,
                           backprop_quantization_style=style)
 
 
-def test_multi_equals_per_tensor_loop():
-    a, b = make('multi'), make('per_tensor')
+@pytest.mark.parametrize('bucket', [256, None])
+def test_multi_equals_per_tensor_loop(bucket):
+    a, b = make('multi', bucket=bucket), make('per_tensor', bucket=bucket)
     torch.backends.cudnn.deterministic = True
     losses = []
     for step in range(3):

@@ -351,7 +351,7 @@ def test_multi_tensor_matches_per_tensor():
     from quantized_distillation_amd.multi_tensor import MultiTensorQuantizer
     g = torch.Generator().manual_seed(9)
     shapes = [(500, 1600), (50, 75, 5, 5), (50,), (10,), (1,), (257,), (256,), (50, 50, 5, 5), (3, 3), (1025,)]
-    for bucket in (256, 128, 100):
+    for bucket in (256, 128, 100, None):
         masters = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
         mt = MultiTensorQuantizer(masters, 16, bucket)
         outs = mt.quantize()
