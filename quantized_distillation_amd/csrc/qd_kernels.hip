@@ -287,15 +287,15 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
             const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
             f4 v[U][V];
             float a_keep = 0.0f, b_keep = 0.0f;
-    #pragma unroll
+#pragma unroll
             for (int uu = 0; uu < U; ++uu) {
                 if (bkt0 + uu < p.nvec) {
                     const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
                 }
             }
-    #pragma unroll
+#pragma unroll
             for (int uu = 0; uu < U; ++uu) {
                 const int64_t bkt = bkt0 + uu;
                 if (bkt < p.nvec) {
@@ -304,11 +304,11 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                     if (prescaled) {
                         a = p.alpha[bkt]; b = p.beta[bkt];
                     } else {
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
                         float mn = fminf(fminf(v[uu][0].x, v[uu][0].y), fminf(v[uu][0].z, v[uu][0].w));
                         float mx = fmaxf(fmaxf(v[uu][0].x, v[uu][0].y), fmaxf(v[uu][0].z, v[uu][0].w));
-    #pragma unroll
+#pragma unroll
                         for (int j = 1; j < V; ++j) {
                             mn = fminf(mn, fminf(fminf(v[uu][j].x, v[uu][j].y), fminf(v[uu][j].z, v[uu][j].w)));
                             mx = fmaxf(mx, fmaxf(fmaxf(v[uu][j].x, v[uu][j].y), fmaxf(v[uu][j].z, v[uu][j].w)));
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                         if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
                     }
                     f4* dst = (f4*)(p.out + e0);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < V; ++j) {
                         const int64_t e = e0 + (int64_t)j * LPB * 4;
                         float rnd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -351,11 +351,11 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
             if (prescaled) {
                 a = p.alpha[bkt]; b = p.beta[bkt];
             } else {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
                 float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
                 float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
-    #pragma unroll
+#pragma unroll
                 for (int j = 1; j < V; ++j) {
                     mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
                     mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                 if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
             }
             f4* dst = (f4*)(p.out + e0);
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < V; ++j) {
                 const int64_t e = e0 + (int64_t)j * LPB * 4;
                 float rnd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -388,20 +388,20 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
             if (bkt0 + U <= p.nvec) {
                 // whole group in range (every tile but possibly the last): unpredicated, all loads first
                 f4 v[U][V];
-    #pragma unroll
+#pragma unroll
                 for (int uu = 0; uu < U; ++uu) {
                     const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
                 }
-    #pragma unroll
+#pragma unroll
                 for (int uu = 0; uu < U; ++uu) process(v[uu], bkt0 + uu, uu, a_keep, b_keep);
             } else {
                 for (int uu = 0; uu < U; ++uu) {
                     if (bkt0 + uu < p.nvec) {
                         f4 v[V];
                         const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * LPB);
                         process(v, bkt0 + uu, uu, a_keep, b_keep);
                     }
