@@ -9,8 +9,11 @@ from hypothesis import strategies as st
 import quantization
 from oracle import oracle_c as oc
 
+import os
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+SOAK = int(os.environ.get('QD_SOAK', '1'))        # QD_SOAK=10 multiplies the number of examples (soak runs)
 
 buckets = st.sampled_from([None, 256, 256, 64, 128, 512, 1024, 2048, 4096, 100, 7, 1, 33, 1000])
 sizes = st.one_of(st.integers(1, 5000), st.integers(5000, 300000))
@@ -34,7 +37,7 @@ def make(n, seed, kind):
     return x.astype(np.float32)
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=60 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
 @given(n=sizes, bucket=buckets, s=levels, seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 5),
        clamp=st.sampled_from([False, False, 0.5, 2.0]))
 def test_uniform_matches_oracle(n, bucket, s, seed, kind, clamp):
@@ -48,7 +51,7 @@ def test_uniform_matches_oracle(n, bucket, s, seed, kind, clamp):
     assert np.array_equal(sf.idx_max_rows.cpu().numpy().reshape(-1), r['imax'])
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=40 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
 @given(n=sizes, bucket=buckets, k=st.sampled_from([1, 2, 3, 4, 5, 16, 17, 64, 200, 600]), seed=st.integers(0, 2 ** 31 - 1),
        kind=st.integers(0, 3), dup=st.booleans())
 def test_nonuniform_matches_oracle(n, bucket, k, seed, kind, dup):
@@ -71,3 +74,32 @@ def test_nonuniform_matches_oracle(n, bucket, k, seed, kind, dup):
     _, gp = fn.backward(torch.from_numpy(g).to(DEV))
     want, absum = oc.point_grad(g, rm['idx'], rm['alpha'], bucket, k)
     assert np.all(np.abs(gp.cpu().numpy().astype(np.float64) - want) <= 4e-6 * absum + 1e-30)
+
+
+@settings(max_examples=30 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=sizes, bucket=st.sampled_from([64, 128, 256, 512, 1024, 2048]), sb=st.sampled_from([(2, 1), (3, 2), (4, 2), (9, 4), (16, 4), (16, 8), (256, 8)]),
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 5))
+def test_pack_unpack_matches_quantizer(n, bucket, sb, seed, kind):
+    from quantized_distillation_amd import codec
+    s, bits = sb
+    x = make(n, seed, kind)
+    xd = torch.from_numpy(x).to(DEV)
+    pk = codec.pack_uniform(xd, s, bucket, bits=bits)
+    q, _ = quantization.uniformQuantization(xd, s, bucket_size=bucket)
+    assert torch.equal(pk.unpack(), q)
+    r = oc.uniform_quantize(x, s, bucket)
+    assert np.array_equal(codec.level_histogram(xd, s, bucket).cpu().numpy(), np.bincount(r['lev'], minlength=s))
+
+
+@settings(max_examples=30 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=sizes, bucket=st.sampled_from([64, 128, 256, 512, 1024, 100, 7]), s=st.sampled_from([2, 4, 16, 256]),
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 3))
+def test_ste_backward_matches_oracle(n, bucket, s, seed, kind):
+    x = make(n, seed, kind)
+    g = np.random.RandomState(seed ^ 77).randn(n).astype(np.float32)
+    fn = quantization.uniformQuantization_variable(s, bucket_size=bucket)
+    fn.forward(torch.from_numpy(x).to(DEV))
+    out = fn.backward(torch.from_numpy(g).to(DEV)).cpu().numpy()
+    ref = oc.ste_complicated_backward(x, g, s, bucket)
+    assert np.array_equal(out != g, ref != g)                    # same positions touched (tie rule)
+    assert np.allclose(out, ref, rtol=0, atol=4e-6 * (np.abs(g).mean() + 1e-30) * min(bucket, n) + 1e-30)
