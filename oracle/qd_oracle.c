@@ -64,11 +64,14 @@ static void bucket_stats(const float* x, int64_t lo, int64_t hi, int sub_mean, f
                          float me, float* alpha, float* beta, int64_t* imin, int64_t* imax) {
     float mn = prep(x[lo], sub_mean, mean, clamp, me), mx = mn;
     int64_t jmn = 0, jmx = 0;
+    int has_nan = mn != mn;
     for (int64_t i = lo + 1; i < hi; ++i) {
         float v = prep(x[i], sub_mean, mean, clamp, me);
+        if (v != v) has_nan = 1;
         if (v < mn) { mn = v; jmn = i - lo; }
         if (v > mx) { mx = v; jmx = i - lo; }
     }
+    if (has_nan) { mn = NAN; mx = NAN; }   /* torch.min/max propagate NaN: the whole bucket becomes NaN */
     float a = mx - mn;
     if (a < QDO_TOL) a = 1.0f;
     *alpha = a; *beta = mn;
@@ -81,6 +84,7 @@ static void global_stats(const float* x, int64_t n, int sub_mean, float mean, in
                          float* alpha, float* beta, int64_t* imin, int64_t* imax) {
     float gmn = INFINITY, gmx = -INFINITY;
     int64_t gjmn = 0, gjmx = 0;
+    int any_nan = 0;
 #pragma omp parallel
     {
         float mn = INFINITY, mx = -INFINITY;
@@ -88,6 +92,10 @@ static void global_stats(const float* x, int64_t n, int sub_mean, float mean, in
 #pragma omp for schedule(static) nowait
         for (int64_t i = 0; i < n; ++i) {
             float v = prep(x[i], sub_mean, mean, clamp, me);
+            if (v != v) {
+#pragma omp atomic write
+                any_nan = 1;
+            }
             if (v < mn) { mn = v; jmn = i; }
             if (v > mx) { mx = v; jmx = i; }
         }
@@ -97,6 +105,7 @@ static void global_stats(const float* x, int64_t n, int sub_mean, float mean, in
             if (jmx != INT64_MAX && (mx > gmx || (mx == gmx && jmx < gjmx))) { gmx = mx; gjmx = jmx; }
         }
     }
+    if (any_nan) { gmn = NAN; gmx = NAN; }
     float a = gmx - gmn;
     if (a < QDO_TOL) a = 1.0f;
     *alpha = a; *beta = gmn;

@@ -49,7 +49,11 @@ __global__ __launch_bounds__(256) void k_pack_vec(const float* x, uint8_t* packe
             mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
             mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
         }
+        bool nan = false;
+#pragma unroll
+        for (int j = 0; j < V; ++j) nan |= has_nan4(v[j]);
         if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); } else { mn = wave_min(mn); mx = wave_max(mx); }
+        if (group_any<LPB>(nan)) { mn = NAN; mx = NAN; }   // a NaN bucket has NaN alpha/beta (its indices are meaningless)
         float a, b;
         alpha_beta(mn, mx, a, b);
         if (l == 0) { alpha[bkt] = a; beta[bkt] = b; }
@@ -79,8 +83,10 @@ __global__ __launch_bounds__(64) void k_pack_tail(const float* x, uint8_t* packe
                                                   int64_t lo, int64_t n, int64_t bkt, float sm1) {
     const int lane = threadIdx.x;
     float mn = INFINITY, mx = -INFINITY;
-    for (int64_t i = lo + lane; i < n; i += 64) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    bool nan = false;
+    for (int64_t i = lo + lane; i < n; i += 64) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); nan |= (v != v); }
     mn = wave_min(mn); mx = wave_max(mx);
+    if (group_any<64>(nan)) { mn = NAN; mx = NAN; }
     float a, b;
     alpha_beta(mn, mx, a, b);
     if (lane == 0) { alpha[bkt] = a; beta[bkt] = b; }

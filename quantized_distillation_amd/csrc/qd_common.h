@@ -124,6 +124,19 @@ __device__ __forceinline__ f4 prep4(f4 v, const Prep& p) {
     return v;
 }
 
+// NaN poisoning: torch's min/max propagate NaN, so one NaN makes alpha, beta and every output of its
+// bucket NaN in the reference; v_min/v_max drop NaNs, so the flag is carried separately.  (Infinities
+// need nothing: alpha = inf or beta = -inf turn the bucket into NaN through the same arithmetic.)
+__device__ __forceinline__ bool has_nan4(const f4& v) { return (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w); }
+// true for every lane of a LANES-wide group (16 = DPP row, 64 = wave) if any lane of it raised `flag`
+template <int LANES>
+__device__ __forceinline__ bool group_any(bool flag) {
+    const unsigned long long m = __ballot(flag);
+    if (LANES == 64) return m != 0ull;
+    const int lane = threadIdx.x & 63;
+    return ((m >> (lane & 48)) & 0xFFFFull) != 0ull;
+}
+
 // alpha/beta of a bucket from its min/max (quant_functions.py:91-99)
 __device__ __forceinline__ void alpha_beta(float mn, float mx, float& a, float& b) {
     a = mx - mn;

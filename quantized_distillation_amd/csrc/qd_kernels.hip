@@ -158,12 +158,15 @@ __device__ __forceinline__ void bucket_lanes(const KParams& p, const PointTable*
         a = p.alpha[bkt]; b = p.beta[bkt];
     } else {
         float mn = INFINITY, mx = -INFINITY;
+        bool nan = false;
         for (int64_t i = lo + l; i < hi; i += LANES) {
             const float v = prep(p.x[i], pp);
             mn = fminf(mn, v); mx = fmaxf(mx, v);
+            nan |= (v != v);
         }
         if (LANES == 16) { mn = row16_min(mn); mx = row16_max(mx); }
         else { mn = wave_min(mn); mx = wave_max(mx); }
+        if (group_any<LANES>(nan)) { mn = NAN; mx = NAN; }
         alpha_beta(mn, mx, a, b);
         if (l == 0) {
             if (p.alpha) p.alpha[bkt] = a;
@@ -211,13 +214,16 @@ __device__ __forceinline__ void bucket_lanes4(const KParams& p, const PointTable
         a = p.alpha[bkt]; b = p.beta[bkt];
     } else {
         float mn = INFINITY, mx = -INFINITY;
+        bool nan = false;
         for (int i = l; i < nv; i += LANES) {
             const f4 v = prep4(src[i], pp);
             mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
             mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            nan |= has_nan4(v);
         }
         if (LANES == 16) { mn = row16_min(mn); mx = row16_max(mx); }
         else { mn = wave_min(mn); mx = wave_max(mx); }
+        if (group_any<LANES>(nan)) { mn = NAN; mx = NAN; }
         alpha_beta(mn, mx, a, b);
         if (l == 0) {
             if (p.alpha) p.alpha[bkt] = a;
@@ -313,8 +319,12 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                             mn = fminf(mn, fminf(fminf(v[uu][j].x, v[uu][j].y), fminf(v[uu][j].z, v[uu][j].w)));
                             mx = fmaxf(mx, fmaxf(fmaxf(v[uu][j].x, v[uu][j].y), fmaxf(v[uu][j].z, v[uu][j].w)));
                         }
+                        bool nan = false;
+#pragma unroll
+                        for (int j = 0; j < V; ++j) nan |= has_nan4(v[uu][j]);
                         if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
                         else { mn = wave_min(mn); mx = wave_max(mx); }
+                        if (group_any<LPB>(nan)) { mn = NAN; mx = NAN; }
                         alpha_beta(mn, mx, a, b);
                         if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
                     }
@@ -360,8 +370,12 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                     mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
                     mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
                 }
+                bool nan = false;
+#pragma unroll
+                for (int j = 0; j < V; ++j) nan |= has_nan4(v[j]);
                 if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
                 else { mn = wave_min(mn); mx = wave_max(mx); }
+                if (group_any<LPB>(nan)) { mn = NAN; mx = NAN; }
                 alpha_beta(mn, mx, a, b);
                 if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
             }
@@ -468,11 +482,14 @@ __global__ __launch_bounds__(1024) void k_bucket_generic(KParams p) {
             a = p.alpha[bkt]; b = p.beta[bkt];
         } else {
             float mn = INFINITY, mx = -INFINITY;
+            int nan = 0;
             for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
                 const float v = prep(p.x[i], pp);
                 mn = fminf(mn, v); mx = fmaxf(mx, v);
+                nan |= (v != v);
             }
             block_minmax(mn, mx, red);
+            if (__syncthreads_or(nan)) { mn = NAN; mx = NAN; }
             alpha_beta(mn, mx, a, b);
             if (threadIdx.x == 0) {
                 if (p.alpha) p.alpha[bkt] = a;
@@ -513,6 +530,7 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float* x, int64_t 
     pp.mean = mean ? *mean : 0.0f;
     pp.me = me;
     float mn = INFINITY, mx = -INFINITY;
+    int nan = 0;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     if ((((uintptr_t)x) & 15) == 0) {
@@ -522,18 +540,22 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float* x, int64_t 
             const f4 v = prep4(x4[i], pp);          // plain load: keep the lines in L2/MALL for stage 3
             mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
             mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            nan |= has_nan4(v);
         }
         for (int64_t i = (n4 << 2) + tid; i < n; i += nth) {
             const float v = prep(x[i], pp);
             mn = fminf(mn, v); mx = fmaxf(mx, v);
+            nan |= (v != v);
         }
     } else {
         for (int64_t i = tid; i < n; i += nth) {
             const float v = prep(x[i], pp);
             mn = fminf(mn, v); mx = fmaxf(mx, v);
+            nan |= (v != v);
         }
     }
     block_minmax(mn, mx, red);
+    if (__syncthreads_or(nan)) { mn = NAN; mx = NAN; }      // NaN poisons the partial (and, in stage 2, the tensor)
     if (threadIdx.x == 0) { part[blockIdx.x] = mn; part[kPartialBlocks + blockIdx.x] = mx; }
 }
 
@@ -543,11 +565,15 @@ __global__ __launch_bounds__(256) void k_minmax_final(const float* part, int npa
                                                       float* alpha_out, float* beta_out) {
     __shared__ float red[32];
     float mn = INFINITY, mx = -INFINITY;
+    int nan = 0;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-        mn = fminf(mn, part[i]);
+        const float pm = part[i];
+        nan |= (pm != pm);
+        mn = fminf(mn, pm);
         mx = fmaxf(mx, part[kPartialBlocks + i]);
     }
     block_minmax(mn, mx, red);
+    if (__syncthreads_or(nan)) { mn = NAN; mx = NAN; }
     if (threadIdx.x == 0) {
         float a, b;
         alpha_beta(mn, mx, a, b);
@@ -1127,7 +1153,11 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* table
                 mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
                 mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
             }
+            bool nan = false;
+#pragma unroll
+            for (int j = 0; j < V; ++j) nan |= has_nan4(v[j]);
             mn = row16_min(mn); mx = row16_max(mx);
+            if (group_any<16>(nan)) { mn = NAN; mx = NAN; }
             float a, b, lev;
             alpha_beta(mn, mx, a, b);
             f4* dst = (f4*)(p.out + lo) + l;

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void k_mg_minmax(const QdTensorDesc* table, in
         const int64_t lo = (t - d.first_tile) * kTile;
         const int64_t hi = lo + kTile < d.n ? lo + kTile : d.n;
         float mn = INFINITY, mx = -INFINITY;
+        bool nan = false;
         if (hi - lo == kTile && ((((uintptr_t)d.x) & 15) == 0)) {
             const f4* src = (const f4*)(d.x + lo) + lane;
 #pragma unroll
@@ -38,11 +39,13 @@ __global__ __launch_bounds__(256) void k_mg_minmax(const QdTensorDesc* table, in
                 const f4 v = src[j * 64];                 // plain loads: phase 3 re-reads from L2 / MALL
                 mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
                 mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                nan |= has_nan4(v);
             }
         } else {
-            for (int64_t i = lo + lane; i < hi; i += 64) { const float v = d.x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+            for (int64_t i = lo + lane; i < hi; i += 64) { const float v = d.x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); nan |= (v != v); }
         }
         mn = wave_min(mn); mx = wave_max(mx);
+        if (group_any<64>(nan)) { mn = NAN; mx = NAN; }       // NaN poisons the tile and, in phase 2, the tensor
         if (lane == 0) { part[2 * t] = mn; part[2 * t + 1] = mx; }
     }
 }
@@ -55,8 +58,14 @@ __global__ __launch_bounds__(256) void k_mg_fold(const QdTensorDesc* table, int 
     const int64_t t0 = table[ti].first_tile;
     const int64_t t1 = ti + 1 < ntensors ? table[ti + 1].first_tile : total_tiles;
     float mn = INFINITY, mx = -INFINITY;
-    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) { mn = fminf(mn, part[2 * t]); mx = fmaxf(mx, part[2 * t + 1]); }
+    int nan = 0;
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
+        const float pm = part[2 * t];
+        nan |= (pm != pm);
+        mn = fminf(mn, pm); mx = fmaxf(mx, part[2 * t + 1]);
+    }
     block_minmax(mn, mx, red);
+    if (__syncthreads_or(nan)) { mn = NAN; mx = NAN; }
     if (threadIdx.x == 0) {
         float a, b;
         alpha_beta(mn, mx, a, b);

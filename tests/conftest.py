@@ -51,6 +51,11 @@ def golden_ste():
 
 
 @pytest.fixture(scope='session')
+def golden_nonfinite():
+    return load_golden('nonfinite.npz')
+
+
+@pytest.fixture(scope='session')
 def golden_misc():
     return load_golden('misc.npz')
 

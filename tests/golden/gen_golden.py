@@ -17,6 +17,7 @@ Outputs (all small, committed):
   uniform.npz      uniformQuantization + ScalingFunction side outputs over a case grid
   nonuniform.npz   nonUniformQuantization (plain and pre-processed) + point gradients
   ste.npz          patched 'complicated' backward
+  nonfinite.npz    uniformQuantization on inputs holding NaN / +-inf
   misc.npz         scale_down / inv_scale_down round trips, initialize_quantization_points,
                    assign_bits_automatically, huffman mean bit length
   big_checksums.json   float64 checksums / histograms of larger runs (no tensors stored)
@@ -336,6 +337,41 @@ def run_misc():
     print('misc done')
 
 
+def run_nonfinite():
+    """NaN / +-inf inputs: torch's min/max propagate NaN and an infinite alpha or beta turns the whole
+    bucket into NaN through the arithmetic -- behaviour worth pinning because v_min/v_max on the
+    GPU drop NaNs unless told otherwise."""
+    out = {}
+    meta = []
+    cases = []
+    for bucket in (256, None, 100):
+        for s in (16, 4):
+            cases.append(dict(n=1000, bucket=bucket, s=s, nan_at=[5], inf_at=[], ninf_at=[]))
+            cases.append(dict(n=1000, bucket=bucket, s=s, nan_at=[], inf_at=[300], ninf_at=[]))
+            cases.append(dict(n=1000, bucket=bucket, s=s, nan_at=[], inf_at=[], ninf_at=[600]))
+            cases.append(dict(n=1000, bucket=bucket, s=s, nan_at=[999], inf_at=[10], ninf_at=[11]))
+    cases.append(dict(n=40000, bucket=None, s=16, nan_at=[39999], inf_at=[], ninf_at=[]))
+    cases.append(dict(n=40000, bucket=None, s=16, nan_at=[], inf_at=[123], ninf_at=[]))
+    for i, c in enumerate(cases):
+        x = torch.randn(c['n'], generator=gen(7000 + i))
+        for j in c['nan_at']:
+            x[j] = float('nan')
+        for j in c['inf_at']:
+            x[j] = float('inf')
+        for j in c['ninf_at']:
+            x[j] = float('-inf')
+        q, sf = refq.uniformQuantization(x, c['s'], bucket_size=c['bucket'])
+        k = 'f%03d_' % i
+        out[k + 'x'] = x.numpy()
+        out[k + 'q'] = q.numpy()
+        out[k + 'alpha'] = sf.alpha.numpy()
+        out[k + 'beta'] = sf.beta.numpy()
+        meta.append(c)
+    out['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'nonfinite.npz'), **out)
+    print('nonfinite cases:', len(meta))
+
+
 def run_big():
     """Checksums of larger runs; inputs are re-creatable from the seed with torch.randn (CPU
     generator streams are identical for the same torch build), and are also re-derivable through
@@ -370,4 +406,5 @@ if __name__ == '__main__':
     run_nonuniform()
     run_ste()
     run_misc()
+    run_nonfinite()
     run_big()

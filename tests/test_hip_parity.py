@@ -509,3 +509,26 @@ def test_abs_scaling_intended_math(kind):
         assert np.all(host(q)[x == 0] == 0)
     with pytest.raises(ValueError):
         quantization.uniformQuantization_variable(16, type_of_scaling=kind, bucket_size=256).backward(dev(x))
+
+
+def test_nonfinite_inputs_golden(golden_nonfinite):
+    """Reference behaviour on NaN / +-inf inputs (NaN poisons its bucket): every path that computes a
+    bucket's min/max -- per-tensor API, scale_down, multi-tensor, codec -- reproduces it."""
+    from quantized_distillation_amd import codec
+    from quantized_distillation_amd.multi_tensor import MultiTensorQuantizer
+    G = golden_nonfinite
+    for i, c in enumerate(G.meta):
+        x = G.arr('f', i, 'x')
+        xd = dev(x)
+        q, sf = quantization.uniformQuantization(xd, c['s'], bucket_size=c['bucket'])
+        assert np.array_equal(host(q), G.arr('f', i, 'q'), equal_nan=True), (i, c)
+        assert np.array_equal(host(sf.alpha), G.arr('f', i, 'alpha'), equal_nan=True), (i, c)
+        assert np.array_equal(host(sf.beta), G.arr('f', i, 'beta'), equal_nan=True), (i, c)
+        out = MultiTensorQuantizer([xd], c['s'], c['bucket']).quantize()[0]
+        assert np.array_equal(host(out), G.arr('f', i, 'q'), equal_nan=True), (i, c)
+        if c['bucket'] == 256:
+            assert np.array_equal(host(codec.pack_uniform(xd, c['s'], 256).alpha), G.arr('f', i, 'alpha').reshape(-1), equal_nan=True)
+        sf2 = quantization.ScalingFunction('linear', False, False, c['bucket'])
+        u = sf2.scale_down(xd)
+        ref = onp.scale_down(x, c['bucket'])
+        assert np.array_equal(host(u), ref['u'], equal_nan=True), (i, c)

@@ -142,3 +142,17 @@ def test_torch_port(golden_uniform):
         q, alpha, beta = uniform_quantize_torch_ops(torch.from_numpy(G.arr('u', i, 'x')), c['s'], c['bucket'])
         assert np.array_equal(q.numpy(), G.arr('u', i, 'q')), (i, c)
         assert np.array_equal(alpha.numpy().reshape(-1), G.arr('u', i, 'alpha').reshape(-1)), (i, c)
+
+
+def test_nonfinite_inputs(golden_nonfinite):
+    """NaN poisons its bucket (torch min/max propagate NaN); +-inf does too, through alpha/beta."""
+    from oracle import oracle_c as oc
+    oc.build()
+    G = golden_nonfinite
+    for i, c in enumerate(G.meta):
+        x = G.arr('f', i, 'x')
+        for r in (onp.uniform_quantize(x, c['s'], c['bucket']), oc.uniform_quantize(x, c['s'], c['bucket'])):
+            assert np.array_equal(r['q'], G.arr('f', i, 'q'), equal_nan=True), (i, c)
+            assert np.array_equal(r['alpha'].reshape(-1), G.arr('f', i, 'alpha').reshape(-1), equal_nan=True), (i, c)
+            assert np.array_equal(r['beta'].reshape(-1), G.arr('f', i, 'beta').reshape(-1), equal_nan=True), (i, c)
+        assert np.isnan(G.arr('f', i, 'q')).any()
