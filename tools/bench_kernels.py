@@ -70,6 +70,12 @@ def k1s(i):
 
 timeit('K1  uniform 4-bit bucket 256 (API)', k1, 8)
 timeit('K1  uniform 2-bit bucket 256 (API)', k1_2bit, 8)
+xr = [torch.randn(N + 17, device=dev) for _ in range(R)]
+timeit('K1  uniform 4-bit bucket 256, ragged N = 64Mi+17', lambda i: live.__setitem__(i % R, quantization.uniformQuantization(xr[i % R], 16, bucket_size=256)[0]), 8, n=N + 17)
+del xr
+xw = [0.05 * torch.randn(N, device=dev) for _ in range(R)]
+timeit('K1  uniform 4-bit bucket 256, weight-like 0.05*randn', lambda i: live.__setitem__(i % R, quantization.uniformQuantization(xw[i % R], 16, bucket_size=256)[0]), 8)
+del xw
 timeit('K1g uniform 4-bit no buckets (API, 3 launches)', k1g, 12)
 timeit('K1s uniform 4-bit bucket 256 stochastic', k1s, 8)
 for b in (64, 128, 512, 1024, 2048, 100):
