@@ -122,3 +122,25 @@ def test_percentile_from_sorted_is_numpy_exact():
         s = np.sort(x)
         got = qhf.percentile_points_from_sorted(lambda i: s[i], n, k)
         assert np.array_equal(got, np.percentile(x, np.linspace(0, 100, num=k))), (n, k)
+
+
+def test_checkpoint_formats_roundtrip(tmp_path):
+    """The two on-disk formats the reference's evaluation scripts read (cifar10_test.py:265-270,
+    model_manager.py:182-190): plain pickles of Python lists/dicts + torch.save state dicts."""
+    import pickle
+    from harness import checkpoints, models
+    net = models.student()
+    pts = torch.sort(torch.rand(22, 4), dim=1)[0]
+    base = str(tmp_path / 'quant_points_2bits')
+    checkpoints.save_quantization_points(base, pts, {'predictionAccuracy': [0.5], 'numEpochsTrained': 1}, net.state_dict())
+    with open(base, 'rb') as f:                        # exactly what the reference's reader does
+        raw_points, info = pickle.load(f)
+    assert isinstance(raw_points, list) and len(raw_points) == 22 and isinstance(raw_points[0][0], float)
+    assert info['numEpochsTrained'] == 1
+    p2, _, sd = checkpoints.load_quantization_points(base)
+    assert np.allclose(np.array(p2, dtype=np.float32), pts.numpy())
+    net.load_state_dict(sd)
+    run = str(tmp_path / 'student1')
+    checkpoints.save_training_run(run, net, {'numBits': 4, 'bucket_size': 256}, {'lossSaved': [1.0]})
+    sd2, args, info2 = checkpoints.load_training_run(run)
+    assert args['numBits'] == 4 and info2['lossSaved'] == [1.0] and set(sd2) == set(net.state_dict())
