@@ -25,7 +25,7 @@ rows = []
 
 
 def timeit(name, fn, bytes_per_elem, iters=40, n=N, note=''):
-    for i in range(5):
+    for i in range(min(iters, 30)):            # long enough to be past the idle-to-busy clock transient
         fn(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
