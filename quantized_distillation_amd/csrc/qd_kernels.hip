@@ -1208,13 +1208,15 @@ inline void geometry(int64_t n, int64_t bucket, int64_t& nb, int64_t& row) {
 }
 
 inline int grid_cap() {
-    // Measured on MI355X (tools/tune_k1.py, profiles/): one wave-tile per wave (no grid-stride
+    // Measured on MI355X (tools/tune_k1.py, profiles/r01_tune.txt): one wave-tile per wave (no grid-stride
     // reuse) streams fastest -- 85.9 us vs 97 us at 2048 persistent blocks for the 64 Mi-element
-    // headline tensor -- so the cap only bounds the grid dimension.  QD_GRID_CAP overrides it
-    // (tuning experiments only).
+    // headline tensor -- so the cap only bounds the grid dimension.
+#ifdef QD_TUNING        // launch-geometry experiments only (build with -DQD_TUNING): QD_GRID_CAP=<blocks>
     const char* e = getenv("QD_GRID_CAP");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : (1 << 20);
+    if (v > 0) return v;
+#endif
+    return 1 << 20;
 }
 inline int blocks_for(int64_t items, int per_block) {
     int64_t b = (items + per_block - 1) / per_block;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the headline kernel under different launch geometries (QD_GRID_CAP), next to
 torch's device copy of the same bytes.  Interleaved rounds in one process; prints a table.
+Needs a library built with -DQD_TUNING (the QD_GRID_CAP hook is compiled out of the product build).
 Run on the GPU box:  python tools/tune_k1.py"""
 import os
 import sys
