@@ -92,6 +92,32 @@ __device__ __forceinline__ long long wave_min_ll(long long v) {
     return v;
 }
 
+// all-reduce over a group of LANES lanes (16 = DPP row, 32 = half wave, 64 = wave)
+template <int LANES> __device__ __forceinline__ float group_min(float v) {
+    v = row16_min(v);
+    if (LANES >= 32) v = fminf(v, __shfl_xor(v, 16));
+    if (LANES >= 64) v = fminf(v, __shfl_xor(v, 32));
+    return v;
+}
+template <int LANES> __device__ __forceinline__ float group_max(float v) {
+    v = row16_max(v);
+    if (LANES >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if (LANES >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+template <int LANES> __device__ __forceinline__ float group_sum(float v) {
+    v = row16_sum(v);
+    if (LANES >= 32) v = v + __shfl_xor(v, 16);
+    if (LANES >= 64) v = v + __shfl_xor(v, 32);
+    return v;
+}
+template <int LANES> __device__ __forceinline__ int group_imin(int v) {
+    v = row16_imin(v);
+    if (LANES >= 32) v = min(v, __shfl_xor(v, 16));
+    if (LANES >= 64) v = min(v, __shfl_xor(v, 32));
+    return v;
+}
+
 // block-wide all-reduce helpers (blockDim.x a multiple of 64, <= 1024); `red` is LDS scratch of
 // >= 32 floats; results are broadcast to every thread.
 __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red) {

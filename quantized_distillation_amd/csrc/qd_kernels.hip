@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
             mn = fminf(mn, fminf(fminf(xv[j].x, xv[j].y), fminf(xv[j].z, xv[j].w)));
             mx = fmaxf(mx, fmaxf(fmaxf(xv[j].x, xv[j].y), fmaxf(xv[j].z, xv[j].w)));
         }
-        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); } else { mn = wave_min(mn); mx = wave_max(mx); }
+        mn = group_min<LPB>(mn); mx = group_max<LPB>(mx);
         float a, b, lev;
         alpha_beta(mn, mx, a, b);
         float qmn = INFINITY, qmx = -INFINITY;
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
             qmn = fminf(qmn, fminf(fminf(qv[j].x, qv[j].y), fminf(qv[j].z, qv[j].w)));
             qmx = fmaxf(qmx, fmaxf(fmaxf(qv[j].x, qv[j].y), fmaxf(qv[j].z, qv[j].w)));
         }
-        if (LPB == 16) { qmn = row16_min(qmn); qmx = row16_max(qmx); } else { qmn = wave_min(qmn); qmx = wave_max(qmx); }
+        qmn = group_min<LPB>(qmn); qmx = group_max<LPB>(qmx);
         float aq, bq;
         alpha_beta(qmn, qmx, aq, bq);                       // scale_down of the QUANTIZED bucket, :350
         float sum = 0.0f;
@@ -970,10 +970,11 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
             const int base = (j * LPB + l) * 4;
 #define QD_STE_ELEM(c, off)                                                          \
             {                                                                        \
-                float qs = qv[j].c - bq;  qs = qs / aq;                              \
-                float u = xv[j].c - bq;   u = u / aq;                                \
-                const float d = qs - u;                                              \
-                sum += gv[j].c * d;                                                  \
+                /* qs - u = ((q-bq) - (x-bq))/aq = (q-x)/aq: the division by the bucket's aq is */ \
+                /* applied once to the bucket sum below instead of twice per element (the kernel */ \
+                /* was VALU-bound: 4 IEEE divisions per element); S is compared with a tolerance, */ \
+                /* the touched positions stay integer-exact */                        \
+                sum += gv[j].c * (qv[j].c - xv[j].c);                                \
                 const bool top = ref_tie ? (qv[j].c == qmx) : (xv[j].c == mx);       \
                 const bool bot = ref_tie ? (qv[j].c == qmn) : (xv[j].c == mn);       \
                 jmax = (top && base + off < jmax) ? base + off : jmax;               \
@@ -982,12 +983,7 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
             QD_STE_ELEM(x, 0) QD_STE_ELEM(y, 1) QD_STE_ELEM(z, 2) QD_STE_ELEM(w, 3)
 #undef QD_STE_ELEM
         }
-        if (LPB == 16) { sum = row16_sum(sum); jmax = row16_imin(jmax); jmin = row16_imin(jmin); }
-        else {
-            sum = wave_sum(sum);
-            jmax = row16_imin(jmax); jmax = min(jmax, __shfl_xor(jmax, 16)); jmax = min(jmax, __shfl_xor(jmax, 32));
-            jmin = row16_imin(jmin); jmin = min(jmin, __shfl_xor(jmin, 16)); jmin = min(jmin, __shfl_xor(jmin, 32));
-        }
+        sum = group_sum<LPB>(sum) / aq; jmax = group_imin<LPB>(jmax); jmin = group_imin<LPB>(jmin);
         const bool touch = jmax != jmin;                    // constant bucket: +S and -S cancel
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -1036,16 +1032,13 @@ __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const floa
             float lev;
             const float xv = x[i];
             const float q = qdq(xv, a, b, sm1, 0.0f, lev);
-            float qs = q - bq;  qs = qs / aq;
-            float u = xv - bq;  u = u / aq;              // (tensor-beta)/alpha with the re-derived pair, :400
-            const float d = qs - u;
-            s += g[i] * d;
+            s += g[i] * (q - xv);                        // (qs - u) * aq; divided by aq once per bucket below, cf. :400
             const bool top = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmx) : (xv == mx);
             const bool bot = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmn) : (xv == mn);
             if (top && (long long)i < jmax) jmax = i;
             if (bot && (long long)i < jmin) jmin = i;
         }
-        s = wave_sum(s);
+        s = wave_sum(s) / aq;
         jmax = wave_min_ll(jmax);
         jmin = wave_min_ll(jmin);
         // pass 4: out = g, +S at jmax, -S at jmin (they cancel when the bucket is constant)
@@ -1498,7 +1491,7 @@ int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64
     if (aligned && nfull > 0) {
         if (row == 64) QD_STE(16, 1)
         else if (row == 128) QD_STE(16, 2)
-        else if (row == 256) QD_STE(16, 4)      // whole-wave (64,1) variant measured no faster (tools/ notes)
+        else if (row == 256) QD_STE(16, 4)      // (32,2) and (64,1) lane groupings measured slower: 169-195 / 182-188 vs 166 us
         else if (row == 512) QD_STE(64, 2)
         else if (row == 1024) QD_STE(64, 4)
     }

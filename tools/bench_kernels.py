@@ -117,8 +117,13 @@ def k7(i):
 
 
 timeit("K7  'complicated' STE backward bucket 256", k7, 12)
-timeit("K8  truncated STE grad mask", lambda i: lib.qd_truncated_ste_f32(xs[i % R].data_ptr(), gs[i % R].data_ptr(), N, 1.0, _lib.stream_ptr()), 8,
-       note='4 B w read + 4 B g write where masked (<= 12)')
+timeit("K8  truncated STE grad mask, 32% of |w| > 1 (adversarial)", lambda i: lib.qd_truncated_ste_f32(xs[i % R].data_ptr(), gs[i % R].data_ptr(), N, 1.0, _lib.stream_ptr()), 12,
+       note='w read + g read-modify-write on 79% of the float4s')
+ws_ = [x * 0.2 for x in xs]
+timeit("K8  truncated STE grad mask, clamped weights (nothing masked)", lambda i: lib.qd_truncated_ste_f32(ws_[i % R].data_ptr(), gs[i % R].data_ptr(), N, 1.0, _lib.stream_ptr()), 4,
+       note='w read only')
+timeit("K8  clamp weights to [-1, 1] (nothing out of range)", lambda i: lib.qd_clamp_f32(ws_[i % R].data_ptr(), N, 1.0, _lib.stream_ptr()), 4, note='w read only')
+del ws_
 
 from quantized_distillation_amd import codec  # noqa: E402
 pks = [None] * R
