@@ -619,15 +619,38 @@ __global__ __launch_bounds__(256) void k_minmax_final(const float* part, int npa
 }
 
 // stage 3: elementwise apply with the single (alpha, beta)
+// ab != null: the pair was finalised by k_minmax_final (huge tensors: many apply blocks).
+// ab == null: every block folds the `nparts` stage-1 partials itself (a few KB from L2) -- one
+// launch fewer for the model-sized tensors, where the call is launch-bound, not bandwidth-bound.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab) {
+__global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab, const float* part, int nparts) {
     __shared__ PointTable Ts;
+    __shared__ float red[32];
     const PointTable* T = nullptr;
     if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
-    const float a = ab[0], b = ab[1];
+    float a, b;
+    if (ab) {
+        a = ab[0]; b = ab[1];
+    } else {
+        float mn = INFINITY, mx = -INFINITY;
+        int nan = 0;
+        for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+            const float pm = part[i];
+            nan |= (pm != pm);
+            mn = fminf(mn, pm);
+            mx = fmaxf(mx, part[kPartialBlocks + i]);
+        }
+        block_minmax(mn, mx, red);
+        if (__syncthreads_or(nan)) { mn = NAN; mx = NAN; }
+        alpha_beta(mn, mx, a, b);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (p.alpha) p.alpha[0] = a;
+            if (p.beta) p.beta[0] = b;
+        }
+    }
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
@@ -1309,6 +1332,7 @@ int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
     Workspace w;
     if (!carve(ws, ws_bytes, w)) return QD_ERR_WORKSPACE_TOO_SMALL;
     const float* ab = nullptr;
+    int nparts = 0;
     if (MODE == MODE_NEAREST && p.prescaled) {
         // alpha/beta are inputs: copy the pair into the scratch slot the apply kernel reads
         (void)hipMemcpyAsync(w.ab, p.alpha, sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1318,11 +1342,14 @@ int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
         int pb = blocks_for(p.n, 256 * 4 * 8);
         if (pb > kPartialBlocks) pb = kPartialBlocks;
         hipLaunchKernelGGL(k_minmax_partial, dim3(pb), dim3(256), 0, st, p.x, p.n, p.mean, p.me, w.minmax_part);
-        hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, st, w.minmax_part, pb, w.ab, p.alpha, p.beta);
-        ab = w.ab;
+        nparts = pb;
+        if (p.n > ((int64_t)8 << 20)) {      // > 32 MB: thousands of apply blocks, fold once in its own launch
+            hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, st, w.minmax_part, pb, w.ab, p.alpha, p.beta);
+            ab = w.ab;
+        }
     }
     const int blocks = blocks_for(p.n, 256 * 4 * 4);
-    hipLaunchKernelGGL((k_single_apply<MODE>), dim3(blocks), dim3(256), 0, st, p, ab);
+    hipLaunchKernelGGL((k_single_apply<MODE>), dim3(blocks), dim3(256), 0, st, p, ab, w.minmax_part, nparts);
     return check_launch();
 }
 
