@@ -51,6 +51,11 @@ def golden_ste():
 
 
 @pytest.fixture(scope='session')
+def golden_nonuniform_options():
+    return load_golden('nonuniform_options.npz')
+
+
+@pytest.fixture(scope='session')
 def golden_nonfinite():
     return load_golden('nonfinite.npz')
 

@@ -17,6 +17,7 @@ Outputs (all small, committed):
   uniform.npz      uniformQuantization + ScalingFunction side outputs over a case grid
   nonuniform.npz   nonUniformQuantization (plain and pre-processed) + point gradients
   ste.npz          patched 'complicated' backward
+  nonuniform_options.npz   nonUniformQuantization with max_element / subtract_mean
   nonfinite.npz    uniformQuantization on inputs holding NaN / +-inf
   misc.npz         scale_down / inv_scale_down round trips, initialize_quantization_points,
                    assign_bits_automatically, huffman mean bit length
@@ -337,6 +338,43 @@ def run_misc():
     print('misc done')
 
 
+def run_nonuniform_options():
+    """nonUniformQuantization / nonUniformQuantization_variable with max_element and subtract_mean
+    (plain and pre-processed): options no driver passes, but part of the signatures."""
+    out = {}
+    meta = []
+    cases = []
+    sd = 12000
+    for shape in [(1000,), (513,), (40, 25)]:
+        for bucket in (None, 256, 100):
+            for (me, sm) in ((0.5, False), (False, True), (1.25, True)):
+                sd += 1
+                cases.append(dict(shape=list(shape), bucket=bucket, max_element=me, subtract_mean=sm, k=5, seed=sd))
+    for i, c in enumerate(cases):
+        x = make_input('randn', tuple(c['shape']), c['seed'])
+        pts = torch.sort(torch.rand(c['k'], generator=gen(c['seed'] + 9)))[0].float()
+        q, idx, sf = refq.nonUniformQuantization(x, pts, max_element=c['max_element'], subtract_mean=c['subtract_mean'],
+                                                 bucket_size=c['bucket'])
+        fn = refq.nonUniformQuantization_variable(max_element=c['max_element'], subtract_mean=c['subtract_mean'],
+                                                  bucket_size=c['bucket'], pre_process_tensors=True, tensor=x)
+        q_pre = fn.forward(None, pts).clone()
+        idx_pre = fn.savedForBackward['indices'].clone()
+        k = 'o%03d_' % i
+        out[k + 'x'] = x.numpy()
+        out[k + 'pts'] = pts.numpy()
+        out[k + 'q'] = q.numpy()
+        out[k + 'idx'] = idx.numpy().astype(np.int64)
+        out[k + 'q_pre'] = q_pre.numpy()
+        out[k + 'idx_pre'] = idx_pre.numpy().astype(np.int64)
+        out[k + 'alpha'] = sf.alpha.numpy()
+        m = dict(c)
+        m['mean'] = float(sf.mean_tensor)
+        meta.append(m)
+    out['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'nonuniform_options.npz'), **out)
+    print('nonuniform option cases:', len(meta))
+
+
 def run_nonfinite():
     """NaN / +-inf inputs: torch's min/max propagate NaN and an infinite alpha or beta turns the whole
     bucket into NaN through the arithmetic -- behaviour worth pinning because v_min/v_max on the
@@ -406,5 +444,6 @@ if __name__ == '__main__':
     run_nonuniform()
     run_ste()
     run_misc()
+    run_nonuniform_options()
     run_nonfinite()
     run_big()

@@ -532,3 +532,28 @@ def test_nonfinite_inputs_golden(golden_nonfinite):
         u = sf2.scale_down(xd)
         ref = onp.scale_down(x, c['bucket'])
         assert np.array_equal(host(u), ref['u'], equal_nan=True), (i, c)
+
+
+def test_nonuniform_options_golden(golden_nonuniform_options):
+    """max_element / subtract_mean through nonUniformQuantization and the pre-processed variable."""
+    G = golden_nonuniform_options
+    for i, c in enumerate(G.meta):
+        x, pts = G.arr('o', i, 'x'), G.arr('o', i, 'pts')
+        xd, pd = dev(x), dev(pts)
+        q, idx, sf = quantization.nonUniformQuantization(xd, pd, max_element=c['max_element'],
+                                                         subtract_mean=c['subtract_mean'], bucket_size=c['bucket'])
+        fn = quantization.nonUniformQuantization_variable(max_element=c['max_element'], subtract_mean=c['subtract_mean'],
+                                                          bucket_size=c['bucket'], pre_process_tensors=True, tensor=xd)
+        qp = fn.forward(None, pd)
+        ip = fn.savedForBackward['indices']
+        if c['subtract_mean']:
+            m = float(sf.mean_tensor)
+            assert abs(m - c['mean']) <= 2e-7 * max(1.0, abs(c['mean'])) + 1e-9
+            r = onp.nonuniform_quantize(x, pts, c['bucket'], 'distance', c['max_element'], True, mean=m)
+            assert np.array_equal(host(idx), r['idx']) and np.array_equal(host(q), r['q']), (i, c)
+            m2 = float(fn.scaling_function.mean_tensor)
+            r2 = onp.nonuniform_quantize(x, pts, c['bucket'], 'midpoint', c['max_element'], True, mean=m2)
+            assert np.array_equal(host(ip), r2['idx']) and np.array_equal(host(qp), r2['q']), (i, c)
+        else:
+            assert np.array_equal(host(idx), G.arr('o', i, 'idx')) and np.array_equal(host(q), G.arr('o', i, 'q')), (i, c)
+            assert np.array_equal(host(ip), G.arr('o', i, 'idx_pre')) and np.array_equal(host(qp), G.arr('o', i, 'q_pre')), (i, c)

@@ -156,3 +156,15 @@ def test_nonfinite_inputs(golden_nonfinite):
             assert np.array_equal(r['alpha'].reshape(-1), G.arr('f', i, 'alpha').reshape(-1), equal_nan=True), (i, c)
             assert np.array_equal(r['beta'].reshape(-1), G.arr('f', i, 'beta').reshape(-1), equal_nan=True), (i, c)
         assert np.isnan(G.arr('f', i, 'q')).any()
+
+
+def test_nonuniform_options(golden_nonuniform_options):
+    """max_element / subtract_mean on the non-uniform path; bit-exact given the reference's mean."""
+    G = golden_nonuniform_options
+    for i, c in enumerate(G.meta):
+        x, pts = G.arr('o', i, 'x'), G.arr('o', i, 'pts')
+        mean = c['mean'] if c['subtract_mean'] else None
+        for mode, qk, ik in (('distance', 'q', 'idx'), ('midpoint', 'q_pre', 'idx_pre')):
+            r = onp.nonuniform_quantize(x, pts, c['bucket'], mode, c['max_element'], c['subtract_mean'], mean=mean)
+            assert np.array_equal(r['idx'], G.arr('o', i, ik)), (i, c, mode)
+            assert np.array_equal(r['q'], G.arr('o', i, qk)), (i, c, mode)
