@@ -19,6 +19,10 @@ buckets = st.sampled_from([None, 256, 256, 64, 128, 512, 1024, 2048, 4096, 100, 
 sizes = st.one_of(st.integers(1, 5000), st.integers(5000, 300000))
 levels = st.sampled_from([2, 3, 4, 7, 16, 16, 255, 256, 1000])
 
+# the default run draws a fixed example sequence (the same cases on every box); soak runs explore
+settings.register_profile('qd', derandomize=(SOAK == 1), database=None)
+settings.load_profile('qd')
+
 
 def make(n, seed, kind):
     rng = np.random.RandomState(seed)
@@ -101,5 +105,19 @@ def test_ste_backward_matches_oracle(n, bucket, s, seed, kind):
     fn.forward(torch.from_numpy(x).to(DEV))
     out = fn.backward(torch.from_numpy(g).to(DEV)).cpu().numpy()
     ref = oc.ste_complicated_backward(x, g, s, bucket)
-    assert np.array_equal(out != g, ref != g)                    # same positions touched (tie rule)
-    assert np.allclose(out, ref, rtol=0, atol=4e-6 * (np.abs(g).mean() + 1e-30) * min(bucket, n) + 1e-30)
+    atol = 4e-6 * (np.abs(g).mean() + 1e-30) * min(bucket, n) + 1e-30
+    assert np.allclose(out, ref, rtol=0, atol=atol)
+    # tie rule: only the first arg-min / arg-max of each bucket of the QUANTIZED tensor may be touched.  (A
+    # correction below half an ulp of g leaves g unchanged, and whether it does depends on the summation
+    # order, so "touched" is compared as a subset plus the positions whose correction is clearly visible.)
+    q = oc.uniform_quantize(x, s, bucket)['q']
+    row = min(bucket, n)
+    nb = -(-n // row)
+    qp = np.concatenate([q, np.full(nb * row - n, q[-1], np.float32)]).reshape(nb, row)
+    base = np.arange(nb) * row
+    allowed = np.zeros(nb * row, bool)
+    allowed[base + qp.argmin(1)] = True
+    allowed[base + qp.argmax(1)] = True
+    assert not np.any((out != g) & ~allowed[:n])
+    visible = np.abs(ref - g) > 4 * atol + 4 * np.spacing(np.abs(g))
+    assert np.all((out != g)[visible])
