@@ -153,45 +153,94 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, float* y,
     }
 }
 
-// histogram of uint8 symbols: every lane counts into a private LDS column (k <= 64) -- plain
-// read-increment-write, no atomics -- or into per-block LDS atomics (k <= 256); per-block totals
-// go to the global uint64 histogram with one atomic per bin per block.
-template <bool PRIVATE>
+// histogram of uint8 symbols.  Every lane counts into a private LDS column cnt[k][256] -- plain
+// read-increment-write, no atomics -- of uint32 (k <= 64, 64 KiB) or uint16 (k <= 256, 128 KiB:
+// a lane flushes before it can have seen 65535 symbols).  The four symbols of a 32-bit word are
+// counted together: four independent LDS reads, duplicates resolved in registers (every symbol
+// gets old + multiplicity, so equal addresses are written with equal values), four writes -- one
+// LDS round trip per word instead of four dependent ones, which is what bounds the large tables
+// that leave four waves per CU.  Per-block totals go to the global uint64 histogram with one
+// atomic per bin per block; the grid is resident (as many blocks as fit the CUs at once).
+template <typename CT, int U>
 __global__ __launch_bounds__(256) void k_hist_u8(const uint8_t* idx, int64_t n, int k, unsigned long long* hist) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];       // PRIVATE: [k][256], else [k]
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    const int cells = PRIVATE ? k * 256 : k;
-    for (int j = threadIdx.x; j < cells; j += 256) cnt[j] = 0;
-    __syncthreads();
-    auto bump = [&](uint32_t s) {
-        if (s < (uint32_t)k) {
-            if (PRIVATE) cnt[s * 256 + threadIdx.x] += 1;
-            else atomicAdd(&cnt[s], 1u);
-        }
+    extern __shared__ __attribute__((aligned(16))) unsigned char hist_lds[];
+    CT* cnt = (CT*)hist_lds;                                               // [k + 1][256], row k = dummy
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * 256;
+    CT* col = cnt + threadIdx.x;
+    auto clear = [&]() {
+        uint32_t* z = (uint32_t*)hist_lds;
+        const int words = (k + 1) * 256 * (int)sizeof(CT) / 4;
+        for (int j = threadIdx.x; j < words; j += 256) z[j] = 0;
+        __syncthreads();
     };
+    auto flush = [&]() {                     // 256 / kk threads per bin, rotated start, fixed shuffle fold
+        __syncthreads();
+        int per = 64;                        // threads per bin: a power of two within one wave, per * k <= 256
+        while (per > 1 && per * k > 256) per >>= 1;
+        const int span = 256 / per;          // columns each of them sums
+        for (int t = threadIdx.x; t < k * per; t += 256) {
+            const int j = t / per, q = t % per;
+            unsigned long long total = 0;
+            for (int c = 0; c < span; ++c) total += cnt[j * 256 + q * span + ((c + j) & (span - 1))];
+            for (int sft = 1; sft < per; sft <<= 1) total += __shfl_xor(total, sft);
+            if (q == 0 && total) atomicAdd(&hist[j], total);
+        }
+        __syncthreads();
+    };
+    // symbols >= k (never produced by the quantizer) land in a dummy row k that the fold ignores: no
+    // predicated stores in the hot loop
+    const uint32_t kk = (uint32_t)k;
+    auto bump = [&](uint32_t s) { col[(s < kk ? s : kk) * 256] += 1; };
+    auto bump_word = [&](uint32_t v) {
+        uint32_t s0 = v & 255, s1 = (v >> 8) & 255, s2 = (v >> 16) & 255, s3 = v >> 24;
+        s0 = s0 < kk ? s0 : kk; s1 = s1 < kk ? s1 : kk; s2 = s2 < kk ? s2 : kk; s3 = s3 < kk ? s3 : kk;
+        CT* a0 = col + s0 * 256; CT* a1 = col + s1 * 256; CT* a2 = col + s2 * 256; CT* a3 = col + s3 * 256;
+        const uint32_t c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
+        const uint32_t e01 = (s0 == s1), e02 = (s0 == s2), e03 = (s0 == s3), e12 = (s1 == s2), e13 = (s1 == s3),
+                       e23 = (s2 == s3);
+        *a0 = (CT)(c0 + 1 + e01 + e02 + e03);
+        *a1 = (CT)(c1 + 1 + e01 + e12 + e13);
+        *a2 = (CT)(c2 + 1 + e02 + e12 + e23);
+        *a3 = (CT)(c3 + 1 + e03 + e13 + e23);
+    };
+    clear();
     int64_t done = 0;
     if ((((uintptr_t)idx) & 15) == 0) {
         const int64_t n16 = n >> 4;
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        for (int64_t i = tid; i < n16; i += nth) {
-            const u4 w = __builtin_nontemporal_load((const u4*)idx + i);
+        // a uint16 column overflows after 65535 symbols: at most 4000 16-byte loads per lane between flushes
+        const int64_t epoch = sizeof(CT) == 2 ? (int64_t)4000 * nth : n16 + nth;
+        for (int64_t base = 0; base < n16; base += epoch) {
+            const int64_t end = base + epoch < n16 ? base + epoch : n16;
+            int64_t i = base + tid;
+            for (; i + (int64_t)(U - 1) * nth < end; i += (int64_t)U * nth) {
+                u4 w[U];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t v = c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w;
-                bump(v & 255); bump((v >> 8) & 255); bump((v >> 16) & 255); bump(v >> 24);
+                for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load((const u4*)idx + i + (int64_t)u * nth);
+                __builtin_amdgcn_sched_barrier(0);      // keep the U loads in flight together (not sunk to their uses)
+#pragma unroll
+                for (int u = 0; u < U; ++u) { bump_word(w[u].x); bump_word(w[u].y); bump_word(w[u].z); bump_word(w[u].w); }
             }
+            for (; i < end; i += nth) {
+                const u4 w = __builtin_nontemporal_load((const u4*)idx + i);
+                bump_word(w.x); bump_word(w.y); bump_word(w.z); bump_word(w.w);
+            }
+            if (end < n16) { flush(); clear(); }
         }
         done = n16 << 4;
     }
-    for (int64_t i = done + tid; i < n; i += nth) bump(idx[i]);
-    __syncthreads();
-    for (int j = threadIdx.x; j < k; j += 256) {
-        unsigned long long total = 0;
-        if (PRIVATE) { for (int c = 0; c < 256; ++c) total += cnt[j * 256 + ((c + j) & 255)]; }
-        else total = cnt[j];
-        if (total) atomicAdd(&hist[j], total);
+    int tail = 0;
+    for (int64_t b0 = done + (int64_t)blockIdx.x * 256; b0 < n; b0 += nth) {       // block-uniform trip count
+        const int64_t i = b0 + threadIdx.x;
+        if (i < n) bump(idx[i]);
+        if (sizeof(CT) == 2 && ++tail == 60000) { tail = 0; flush(); clear(); }   // unaligned input only
     }
+    flush();
+}
+
+__global__ __launch_bounds__(256) void k_zero_u64(unsigned long long* p, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) p[i] = 0ull;
 }
 
 inline int blocks_for(int64_t items, int per_block, int cap) {
@@ -271,15 +320,30 @@ int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int 
 int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream) {
     if (n < 0 || k < 1 || k > 256 || !hist || (n > 0 && !idx)) return QD_ERR_INVALID_ARGUMENT;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(hist, 0, sizeof(uint64_t) * (size_t)k, st);
+    hipLaunchKernelGGL(k_zero_u64, dim3(1), dim3(256), 0, st, (unsigned long long*)hist, k);   // (a memset node costs more)
     if (n == 0) return (int)hipGetLastError();
-    const int blocks = blocks_for(n, 256 * 16 * 4, 4096);
-    if (k <= 64)
-        hipLaunchKernelGGL(k_hist_u8<true>, dim3(blocks), dim3(256), (size_t)k * 256 * sizeof(uint32_t), st, idx, n, k,
-                           (unsigned long long*)hist);
-    else
-        hipLaunchKernelGGL(k_hist_u8<false>, dim3(blocks), dim3(256), (size_t)k * sizeof(uint32_t), st, idx, n, k,
-                           (unsigned long long*)hist);
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const size_t lds_bytes = (size_t)(k + 1) * 256 * (k <= 64 ? sizeof(uint32_t) : sizeof(uint16_t));
+    int per_cu = (int)((160 * 1024) / lds_bytes);
+    if (per_cu < 1) per_cu = 1;
+    // measured at 64 Mi symbols, k = 16: 43 / 36 / 41 / 61 us at 1 / 2 / 4 / 8 resident blocks per CU (the counting
+    // is VALU/LDS-issue bound, and every block ends with k same-line global atomics)
+    if (per_cu > 2) per_cu = 2;
+    const int blocks = blocks_for(n, 256 * 16 * 4, cus * per_cu);
+    if (k <= 64) {
+        auto kern = k_hist_u8<uint32_t, 4>;
+        if (lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, st, idx, n, k, (unsigned long long*)hist);
+    } else {
+        auto kern = k_hist_u8<uint16_t, 4>;
+        if (lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, st, idx, n, k, (unsigned long long*)hist);
+    }
     return (int)hipGetLastError();
 }
 

@@ -859,9 +859,26 @@ struct PgBins {
             col[id * stride] += m;                          // private column: plain LDS read-add-write
         }
     }
+    // four elements at once, for the large tables that leave one or two waves per CU: the four reads are
+    // independent (one LDS round trip instead of four dependent ones); lanes' duplicates are resolved in
+    // registers -- every element whose index matches gets the same fixed-order sum, so equal addresses are
+    // written with equal values and the result does not depend on the write order.
+    __device__ __forceinline__ void add4_merged(const int (&id)[4], const float (&m)[4]) {
+        float* a0 = col + id[0] * stride; float* a1 = col + id[1] * stride;
+        float* a2 = col + id[2] * stride; float* a3 = col + id[3] * stride;
+        const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
+        const bool e01 = id[0] == id[1], e02 = id[0] == id[2], e03 = id[0] == id[3];
+        const bool e12 = id[1] == id[2], e13 = id[1] == id[3], e23 = id[2] == id[3];
+        const float z = 0.0f;
+        const float s0 = ((m[0] + (e01 ? m[1] : z)) + (e02 ? m[2] : z)) + (e03 ? m[3] : z);
+        const float s1 = (((e01 ? m[0] : z) + m[1]) + (e12 ? m[2] : z)) + (e13 ? m[3] : z);
+        const float s2 = (((e02 ? m[0] : z) + (e12 ? m[1] : z)) + m[2]) + (e23 ? m[3] : z);
+        const float s3 = (((e03 ? m[0] : z) + (e13 ? m[1] : z)) + (e23 ? m[2] : z)) + m[3];
+        *a0 = c0 + s0; *a1 = c1 + s1; *a2 = c2 + s2; *a3 = c3 + s3;
+    }
 };
 
-template <int KR, int IDXB, bool BUCKETED>
+template <int KR, int IDXB, bool BUCKETED, int U, bool MERGE>
 __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const void* idx, const float* alpha, int64_t n,
                                                          int row_shift, int k, float* part /* [grid][k] */) {
     // KR == 0: bins[k][BS] with BS = blockDim.x (256 for k <= 128, 128 for k <= 256, 64 for k <= 512:
@@ -891,20 +908,28 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
         a = BUCKETED ? alpha[(i << 2) >> row_shift] : a_single;
     };
     auto accumulate = [&](const f4& gv, const int (&id)[4], float a) {
-        B.add(id[0], gv.x * a);                              // one fp32 multiply each, :495
-        B.add(id[1], gv.y * a);
-        B.add(id[2], gv.z * a);
-        B.add(id[3], gv.w * a);
+        const float m[4] = {gv.x * a, gv.y * a, gv.z * a, gv.w * a};     // one fp32 multiply each, :495
+        if (KR == 0 && MERGE) {
+            B.add4_merged(id, m);
+        } else {
+            B.add(id[0], m[0]);
+            B.add(id[1], m[1]);
+            B.add(id[2], m[2]);
+            B.add(id[3], m[3]);
+        }
     };
     int64_t i = tid;
-    for (; i + nth < n4; i += 2 * nth) {                     // two independent float4 in flight per lane
-        f4 ga, gb; int ia[4], ib[4]; float sa, sb;
-        load4(i, ga, ia, sa);
-        load4(i + nth, gb, ib, sb);
-        accumulate(ga, ia, sa);
-        accumulate(gb, ib, sb);
+    for (; i + (int64_t)(U - 1) * nth < n4; i += (int64_t)U * nth) {     // U independent float4 in flight per lane
+        f4 gv[U]; int id[U][4]; float a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load4(i + (int64_t)u * nth, gv[u], id[u], a[u]);
+        // without this the scheduler sinks every load to its first use (to save registers) and the loop pays
+        // one full memory round trip per float4
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) accumulate(gv[u], id[u], a[u]);
     }
-    if (i < n4) {
+    for (; i < n4; i += nth) {
         f4 ga; int ia[4]; float sa;
         load4(i, ga, ia, sa);
         accumulate(ga, ia, sa);
@@ -1258,6 +1283,20 @@ inline void geometry(int64_t n, int64_t bucket, int64_t& nb, int64_t& row) {
     nb = (n + bucket - 1) / bucket;
 }
 
+// compute units of the current device (256 on MI355X); queried once per process
+inline int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
 inline int grid_cap() {
     // Measured on MI355X (tools/tune_k1.py, profiles/r01_tune.txt): one wave-tile per wave (no grid-stride
     // reuse) streams fastest -- 85.9 us vs 97 us at 2048 persistent blocks for the 64 Mi-element
@@ -1506,16 +1545,30 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
         // k <= 4: register bins; otherwise an LDS table [k][threads] of lane-private columns
         const int threads = k <= 128 ? 256 : (k <= 256 ? 128 : 64);
         const size_t lds_bytes = (size_t)(k <= 4 ? 4 * 4 : k * threads) * sizeof(float);
-        if (k > 128 && blocks > 2048) blocks = 2048;      // one resident block per CU: keep partial rows few
-#define QD_PG(KR, IDXB, BK)                                                                                         \
+        // tables above 16 KiB leave few waves per CU: a resident grid (as many blocks as fit the CUs' LDS at
+        // once, so the table is zeroed and folded once per CU), more loads in flight per lane, and the merged
+        // four-element update that needs one LDS round trip per float4 instead of four
+        const bool big = lds_bytes > 16 * 1024;
+        if (big) {
+            const int per_cu = (int)((160 * 1024) / lds_bytes) > 0 ? (int)((160 * 1024) / lds_bytes) : 1;
+            const int resident = num_cus() * per_cu;
+            if (blocks > resident) blocks = resident;
+        }
+#define QD_PG(KR, IDXB, BK, U, MG)                                                                                  \
         {                                                                                                           \
-            auto kern = k_point_grad_fast<KR, IDXB, BK>;                                                            \
+            auto kern = k_point_grad_fast<KR, IDXB, BK, U, MG>;                                                     \
             if (lds_bytes > 64 * 1024)                                                                              \
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(KR > 0 ? 256 : threads), lds_bytes, st, g, idx, alpha, n,   \
                                row_shift, k, w.pg_part);                                                            \
         }
-#define QD_PG_K(IDXB, BK) { if (k <= 4) QD_PG(4, IDXB, BK) else QD_PG(0, IDXB, BK) }
+#define QD_PG_K(IDXB, BK)                                                                                           \
+        {                                                                                                           \
+            if (k <= 4) QD_PG(4, IDXB, BK, 2, false)                                                                \
+            else if (!big) QD_PG(0, IDXB, BK, 2, false)                                                             \
+            else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
+            else QD_PG(0, IDXB, BK, 8, true)                                                                        \
+        }
         if (idx_bytes == 8) { if (nb > 1) QD_PG_K(8, true) else QD_PG_K(8, false) }
         else { if (nb > 1) QD_PG_K(1, true) else QD_PG_K(1, false) }
 #undef QD_PG_K

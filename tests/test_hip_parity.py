@@ -471,6 +471,16 @@ def test_level_histogram_and_device_huffman(golden_misc):
     idx = rng.randint(0, 200, size=1 << 21).astype(np.uint8)
     assert np.array_equal(host(codec.histogram_u8(dev(idx), 256)), np.bincount(idx, minlength=256))
     assert np.array_equal(host(codec.histogram_u8(dev(idx[3:]), 256)), np.bincount(idx[3:], minlength=256))   # unaligned
+    # many k (register duplicates, skipped symbols >= k, every flush geometry), sizes around the resident grid
+    for k in (1, 2, 3, 16, 17, 64, 65, 100, 255, 256):
+        for n in (1, 15, 16, 4099, (1 << 22) + 5):
+            idx = rng.randint(0, 256, size=n).astype(np.uint8)
+            if k < 256:
+                idx[::3] = rng.randint(0, k, size=len(idx[::3]))
+            want = np.bincount(idx, minlength=256)[:k]
+            assert np.array_equal(host(codec.histogram_u8(dev(idx), k)), want), (k, n)
+    runs = np.repeat(np.arange(7, dtype=np.uint8), 100000)                  # long runs: all four bytes of a word equal
+    assert np.array_equal(host(codec.histogram_u8(dev(runs), 256)), np.bincount(runs, minlength=256))
     # same Huffman mean code length as the reference computed through its digitize path
     G = golden_misc
     params = [dev(G.z['hf_p%d' % j]) for j in range(4)]
@@ -478,6 +488,21 @@ def test_level_histogram_and_device_huffman(golden_misc):
         if c['kind'] == 'uniform':
             got = codec.huffman_mean_bit_length_uniform(params, c['s'], c['bucket'])
             assert abs(got - c['mean_bit_length']) < 1e-12, (c, got)
+
+
+def test_histogram_u16_epoch_flush():
+    """k > 64 counts in uint16 columns that are flushed before a lane can have seen 65535 symbols; that only
+    happens beyond ~4.2 G symbols.  A periodic pattern gives the expected counts without a host pass."""
+    from quantized_distillation_amd import codec
+    reps = 18_000_000
+    x = torch.arange(251, dtype=torch.uint8, device=DEV).repeat(reps)      # 4.5 GB
+    h = codec.histogram_u8(x, 256)
+    want = torch.zeros(256, dtype=torch.int64)
+    want[:251] = reps
+    assert torch.equal(h.cpu(), want)
+    h = codec.histogram_u8(x[1:], 256)                                       # unaligned: scalar path, lane-local flush
+    want[0] -= 1
+    assert torch.equal(h.cpu(), want)
 
 
 # ------------------------------------------------------------------------------ absmax / absnorm (parity unpinned)

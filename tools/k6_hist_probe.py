@@ -1,0 +1,45 @@
+"""Timing of the point-gradient kernel (K6) across k and of the uint8 histogram, 64 Mi elements.
+Usage (GPU box): python tools/k6_hist_probe.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import quantization
+from quantized_distillation_amd import codec
+
+dev = 'cuda:0'
+N = 64 << 20
+R = 3
+xs = [torch.randn(N, device=dev) for _ in range(R)]
+gs = [torch.randn(N, device=dev) for _ in range(R)]
+
+
+def timeit(name, fn, iters=30):
+    for i in range(20):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters * 1e3)
+    print('%-44s %8.2f us' % (name, best), flush=True)
+
+
+for i in range(1000):
+    quantization.uniformQuantization(xs[i % R], 16, bucket_size=256)
+torch.cuda.synchronize()
+for k in (4, 8, 16, 17, 32, 64, 128, 256):
+    pts = torch.sort(torch.rand(k, device=dev))[0]
+    fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=xs[j]) for j in range(2)]
+    fns[0].forward(None, pts)
+    fns[1].forward(None, pts)
+    timeit('K6 point gradient k=%d (u8 idx)' % k, lambda i: fns[i % 2].backward(gs[i % R]))
+    del fns
+for k, hi in ((16, 16), (64, 64), (256, 16), (256, 256)):
+    lev = [torch.randint(0, hi, (N,), dtype=torch.uint8, device=dev) for _ in range(R)]
+    timeit('HST uint8 histogram k=%d (symbols < %d)' % (k, hi), lambda i: codec.histogram_u8(lev[i % R], k))
+    del lev
