@@ -15,6 +15,23 @@ typedef int64_t l2 __attribute__((ext_vector_type(2)));
 
 namespace qd {
 
+// ---- explicitly global (address space 1) accesses ----
+// Pointers that a kernel reads out of a descriptor table in memory are generic to the compiler and
+// become flat_load / flat_store (which also occupy the LDS counter); these casts make them global_*.
+#define QD_AS_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ T ldg_nt(const T* p) {
+    return __builtin_nontemporal_load((const QD_AS_GLOBAL T*)p);
+}
+template <typename T> __device__ __forceinline__ void stg_nt(const T& v, T* p) {
+    __builtin_nontemporal_store(v, (QD_AS_GLOBAL T*)p);
+}
+template <typename T> __device__ __forceinline__ T ldg(const T* p) { return *(const QD_AS_GLOBAL T*)p; }
+template <typename T> __device__ __forceinline__ void stg(const T& v, T* p) { *(QD_AS_GLOBAL T*)p = v; }
+// wave index within the grid as a scalar (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
+__device__ __forceinline__ int64_t uniform_wave_index() {
+    return (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
 // ---- DPP row rotations: lane i of each 16-lane row reads lane (i + s) mod 16 of its row ----
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

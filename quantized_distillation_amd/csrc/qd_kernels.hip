@@ -1187,11 +1187,11 @@ __global__ __launch_bounds__(256) void k_truncated_ste(const float* w, float* gr
 // A tile = 4 buckets of one tensor = one wave iteration; a DPP row owns a bucket.  Full, 16-byte
 // aligned 256-element buckets take the register path, everything else the row16 scalar path.
 template <int ROW>
-__global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* table, int ntensors, int64_t total_tiles,
+__global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* __restrict__ table, int ntensors, int64_t total_tiles,
                                                        int64_t bucket, float sm1) {
     const int lane = threadIdx.x & 63;
     const int sub = lane >> 4, l = lane & 15;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave = uniform_wave_index();      // scalar: the table search below runs on s_load
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     Prep pp;
     pp.mean = 0.0f;
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* table
             const f4* src = (const f4*)(p.x + lo) + l;
             f4 v[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * 16);   // masters: read once
+            for (int j = 0; j < V; ++j) v[j] = ldg_nt(src + j * 16);   // masters: read once
             float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
             float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
 #pragma unroll
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* table
                 r.y = qdq(v[j].y, a, b, sm1, 0.0f, lev);
                 r.z = qdq(v[j].z, a, b, sm1, 0.0f, lev);
                 r.w = qdq(v[j].w, a, b, sm1, 0.0f, lev);
-                __builtin_nontemporal_store(r, dst + j * 16);
+                stg_nt(r, dst + j * 16);
             }
         } else {
             bucket_row16<MODE_QDQ>(p, nullptr, bkt, lo, hi, l, pp);

@@ -28,13 +28,13 @@ __device__ __forceinline__ int find_owner(const QdDiffQuantDesc* table, int nten
 
 // forward: a tile = 4 buckets of one tensor = one wave iteration; a DPP row owns a bucket
 template <int ROW>
-__global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* table, int ntensors, int64_t total_tiles,
+__global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* __restrict__ table, int ntensors, int64_t total_tiles,
                                                        int64_t bucket, const float* points, int k) {
     __shared__ float s_pts[4][kMaxK];
     __shared__ float s_mid[4][kMaxK];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sub = lane >> 4, l = lane & 15;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave = uniform_wave_index();      // scalar: find_owner runs on s_load
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t t = wave; t < total_tiles; t += nwaves) {
         const int ti = find_owner(table, ntensors, t, false);          // wave-uniform
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* ta
         if (bkt >= nb) continue;
         const int64_t lo = bkt * row;
         const int64_t hi = lo + row < d.n ? lo + row : d.n;
-        const float a = d.alpha[bkt], b = d.beta[bkt];
+        const float a = ldg(d.alpha + bkt), b = ldg(d.beta + bkt);
         const bool fast = ROW > 0 && (hi - lo) == ROW &&
                           (((((uintptr_t)d.u) | ((uintptr_t)d.q)) & 15) == 0) && ((((uintptr_t)d.idx) & 3) == 0);
         if (fast) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* ta
             f4* dst = (f4*)(d.q + lo) + l;
             f4 v[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * 16);
+            for (int j = 0; j < V; ++j) v[j] = ldg_nt(src + j * 16);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 int id[4];
@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* ta
                 }
                 QD_ONE(x, 0) QD_ONE(y, 1) QD_ONE(z, 2) QD_ONE(w, 3)
 #undef QD_ONE
-                __builtin_nontemporal_store(r, dst + j * 16);
+                stg_nt(r, dst + j * 16);
                 const uint32_t pk = (uint32_t)id[0] | ((uint32_t)id[1] << 8) | ((uint32_t)id[2] << 16) | ((uint32_t)id[3] << 24);
-                *(uint32_t*)(d.idx + lo + ((int64_t)(j * 16 + l) << 2)) = pk;
+                stg(pk, (uint32_t*)(d.idx + lo + ((int64_t)(j * 16 + l) << 2)));
             }
         } else {
             for (int64_t i = lo + l; i < hi; i += 16) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* ta
 }
 
 // backward stage 1: block -> tensor; lane-private LDS columns bins[k][256], plain read-add-write
-__global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc* table, int ntensors, int64_t bucket,
+__global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc* __restrict__ table, int ntensors, int64_t bucket,
                                                           int row_shift, int k, float* part /* [blocks][k] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // [k][256]
     const int ti = find_owner(table, ntensors, blockIdx.x, true);
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc*
     if (vec) {
         const int64_t n4 = d.n >> 2;
         for (int64_t i = tid; i < n4; i += nth) {
-            const f4 gv = __builtin_nontemporal_load((const f4*)d.grad + i);
-            const uint32_t pk = __builtin_nontemporal_load((const uint32_t*)d.idx + i);
-            const float a = single ? a_single : d.alpha[(i << 2) >> row_shift];
+            const f4 gv = ldg_nt((const f4*)d.grad + i);
+            const uint32_t pk = ldg_nt((const uint32_t*)d.idx + i);
+            const float a = single ? a_single : ldg(d.alpha + ((i << 2) >> row_shift));
             col[(pk & 255) * 256] += gv.x * a;           // one fp32 multiply each, quant_functions.py:495
             col[((pk >> 8) & 255) * 256] += gv.y * a;
             col[((pk >> 16) & 255) * 256] += gv.z * a;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc*
 }
 
 // backward stage 2: block (tensor, bin) folds that tensor's partial rows in a fixed order
-__global__ __launch_bounds__(64) void k_multi_point_grad_final(const QdDiffQuantDesc* table, int ntensors,
+__global__ __launch_bounds__(64) void k_multi_point_grad_final(const QdDiffQuantDesc* __restrict__ table, int ntensors,
                                                                int64_t total_blocks, int k, const float* part,
                                                                float* grad_points /* [ntensors][k] */) {
     const int ti = blockIdx.x / k, j = blockIdx.x % k;

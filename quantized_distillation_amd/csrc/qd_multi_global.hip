@@ -22,9 +22,9 @@ __device__ __forceinline__ int owner_of(const QdTensorDesc* table, int ntensors,
 }
 
 // phase 1: per-tile min/max -> part[2*tile], part[2*tile+1]
-__global__ __launch_bounds__(256) void k_mg_minmax(const QdTensorDesc* table, int ntensors, int64_t total_tiles, float* part) {
+__global__ __launch_bounds__(256) void k_mg_minmax(const QdTensorDesc* __restrict__ table, int ntensors, int64_t total_tiles, float* part) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave = uniform_wave_index();      // scalar: owner_of runs on s_load
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t t = wave; t < total_tiles; t += nwaves) {
         const QdTensorDesc d = table[owner_of(table, ntensors, t)];
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_mg_minmax(const QdTensorDesc* table, in
             const f4* src = (const f4*)(d.x + lo) + lane;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f4 v = src[j * 64];                 // plain loads: phase 3 re-reads from L2 / MALL
+                const f4 v = ldg(src + j * 64);           // plain loads: phase 3 re-reads from L2 / MALL
                 mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
                 mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
                 nan |= has_nan4(v);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_mg_minmax(const QdTensorDesc* table, in
 }
 
 // phase 2: one block per tensor folds its tiles into (alpha, beta); the 1e-10 guard on the device
-__global__ __launch_bounds__(256) void k_mg_fold(const QdTensorDesc* table, int ntensors, int64_t total_tiles,
+__global__ __launch_bounds__(256) void k_mg_fold(const QdTensorDesc* __restrict__ table, int ntensors, int64_t total_tiles,
                                                  const float* part, float* ab /* [ntensors][2] */) {
     __shared__ float red[32];
     const int ti = blockIdx.x;
@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void k_mg_fold(const QdTensorDesc* table, int 
 }
 
 // phase 3: apply with the tensor's single (alpha, beta)
-__global__ __launch_bounds__(256) void k_mg_apply(const QdTensorDesc* table, int ntensors, int64_t total_tiles,
+__global__ __launch_bounds__(256) void k_mg_apply(const QdTensorDesc* __restrict__ table, int ntensors, int64_t total_tiles,
                                                   const float* ab, float sm1) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave = uniform_wave_index();      // scalar: owner_of runs on s_load
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t t = wave; t < total_tiles; t += nwaves) {
         const int ti = owner_of(table, ntensors, t);
@@ -89,13 +89,16 @@ __global__ __launch_bounds__(256) void k_mg_apply(const QdTensorDesc* table, int
         if (hi - lo == kTile && (((((uintptr_t)d.x) | ((uintptr_t)d.q)) & 15) == 0)) {
             const f4* src = (const f4*)(d.x + lo) + lane;
             f4* dst = (f4*)(d.q + lo) + lane;
+            f4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ldg_nt(src + j * 64);
+            __builtin_amdgcn_sched_barrier(0);          // all four loads in flight before the first use
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f4 v = __builtin_nontemporal_load(src + j * 64);
                 f4 r;
-                r.x = qdq(v.x, a, b, sm1, 0.0f, lev); r.y = qdq(v.y, a, b, sm1, 0.0f, lev);
-                r.z = qdq(v.z, a, b, sm1, 0.0f, lev); r.w = qdq(v.w, a, b, sm1, 0.0f, lev);
-                __builtin_nontemporal_store(r, dst + j * 64);
+                r.x = qdq(v[j].x, a, b, sm1, 0.0f, lev); r.y = qdq(v[j].y, a, b, sm1, 0.0f, lev);
+                r.z = qdq(v[j].z, a, b, sm1, 0.0f, lev); r.w = qdq(v[j].w, a, b, sm1, 0.0f, lev);
+                stg_nt(r, dst + j * 64);
             }
         } else {
             for (int64_t i = lo + lane; i < hi; i += 64) d.q[i] = qdq(d.x[i], a, b, sm1, 0.0f, lev);
