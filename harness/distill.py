@@ -29,8 +29,12 @@ class DistillTrainer(object):
     def __init__(self, student, teacher, device, num_bits=4, bucket_size=256, lr=1e-3, momentum=0.9,
                  weight_decay=2.2e-4, nesterov=True, quantize_first_and_last_layer=True, mode='multi',
                  backprop_quantization_style='none', grad_chunks=1, overlap_allreduce=False, loss_fn=None,
-                 clip_norm=None):
+                 clip_norm=None, teacher_stream=False):
         self.device = device
+        # optional: the teacher forward (needs neither the quantized weights nor the student) on its own HIP
+        # stream beside quantize + student forward, joined before the KD loss.  Measured on the CIFAR step:
+        # 456 vs 482 steps/s -- the convolution kernels do not overlap -- so it is off by default.
+        self.side = TeacherAhead() if (teacher_stream and torch.device(device).type == 'cuda') else None
         self.student = student.to(device).train()
         self.teacher = teacher.to(device).eval()
         for p in self.teacher.parameters():
@@ -92,7 +96,7 @@ class DistillTrainer(object):
 
     def forward_backward(self, *batch):
         self.flat_grad.zero_()
-        loss = self.loss_fn(self.student, self.teacher, *batch)
+        loss = self.loss_fn(self.student, self.teacher, *batch, side=self.side)
         loss.backward()
         return loss
 
@@ -122,6 +126,7 @@ class DistillTrainer(object):
         update.  The gradient all-reduce stays between the two replays (eager RCCL call), so the
         distributed step is  A.replay(); all_reduce; B.replay().  Only for mode='multi'."""
         assert self.mode == 'multi', 'graph capture needs the persistent-shadow (multi) mode'
+        self.side = None                                 # one captured stream; the graph orders the kernels itself
         self._sx, self._sy = images.clone(), labels.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -149,22 +154,50 @@ class DistillTrainer(object):
         return self._sloss
 
 
-def cnn_kd_loss_fn(student, teacher, images, labels):
+class TeacherAhead(object):
+    """Runs the (gradient-free) teacher forward on a second HIP stream so that its small-shape kernels
+    overlap the student's; `join` makes the current stream wait for it."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+
+    def launch(self, teacher, *inputs):
+        self.stream.wait_stream(torch.cuda.current_stream())         # inputs were produced on the main stream
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            return teacher(*inputs)
+
+    def join(self, out):
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.stream)
+        out.record_stream(cur)                                       # allocated on the side stream, consumed here
+        return out
+
+
+def _teacher_forward(teacher, side, *inputs):
+    """Returns a thunk that yields the teacher output (launched now on the side stream if there is one)."""
+    if side is None:
+        def late():
+            with torch.no_grad():
+                return teacher(*inputs)
+        return late
+    out = side.launch(teacher, *inputs)
+    return lambda: side.join(out)
+
+
+def cnn_kd_loss_fn(student, teacher, images, labels, side=None):
     """Student + teacher forward and the Hinton KD loss (ref: cnn_models/help_fun.py:60-158)."""
+    t_out = _teacher_forward(teacher, side, images)
     out = student(images)
-    with torch.no_grad():
-        t_out = teacher(images)
-    return models.kd_loss(out, t_out, labels)
+    return models.kd_loss(out, t_out(), labels)
 
 
-def seq2seq_kd_loss_fn(student, teacher, src, tgt):
+def seq2seq_kd_loss_fn(student, teacher, src, tgt, side=None):
     """Teacher-forced student + teacher forward and the word-level KD loss
     (ref: translation_models/help_fun.py:36-84, onmt/Loss.py:97-120).  src, tgt: (len, batch)."""
     tgt_in, tgt_out = tgt[:-1], tgt[1:]
+    t_logits = _teacher_forward(teacher, side, src, tgt_in)
     logits = student(src, tgt_in)
-    with torch.no_grad():
-        t_logits = teacher(src, tgt_in)
-    return models.word_kd_loss(logits, t_logits, tgt_out.flatten(), src.size(1))
+    return models.word_kd_loss(logits, t_logits(), tgt_out.flatten(), src.size(1))
 
 
 def synthetic_token_batch(batch, device, seed=0, v_src=18000, v_tgt=10000, max_len=50):

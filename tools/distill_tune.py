@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Harness-side knobs for the CIFAR distillation step (fp32 throughout): MIOpen find mode,
-channels_last.  Prints steps/s for each combination."""
+channels_last, teacher forward on its own stream.  Prints steps/s for each combination."""
 import os
 import sys
 import time
@@ -14,13 +14,13 @@ from harness.distill import DistillTrainer, synthetic_batch  # noqa: E402
 dev = torch.device('cuda:0')
 
 
-def run(bench, cl, steps=150):
+def run(bench, cl, steps=150, teacher_stream=True):
     torch.backends.cudnn.benchmark = bench
     torch.manual_seed(0)
     st, te = models.student(), models.teacher()
     if cl:
         st, te = st.to(memory_format=torch.channels_last), te.to(memory_format=torch.channels_last)
-    tr = DistillTrainer(st, te, dev, num_bits=4, bucket_size=256, mode='multi')
+    tr = DistillTrainer(st, te, dev, num_bits=4, bucket_size=256, mode='multi', teacher_stream=teacher_stream)
     batches = [synthetic_batch(50, dev, seed=i) for i in range(4)]
     if cl:
         batches = [(x.contiguous(memory_format=torch.channels_last), y) for x, y in batches]
@@ -34,6 +34,11 @@ def run(bench, cl, steps=150):
     return steps / (time.perf_counter() - t0)
 
 
+for rep in range(2):
+    for ts in (False, True):
+        print('teacher_stream=%s : %.1f steps/s' % (ts, run(False, False, steps=300, teacher_stream=ts)), flush=True)
+if '--all' not in sys.argv:
+    sys.exit(0)
 for bench in (False, True):
     for cl in (False, True):
         try:
