@@ -13,6 +13,45 @@ import numpy as np
 import torch
 
 
+# ---- hyperspherical-coordinate helpers (ref: help_functions.py:8-64) -------------------------
+# Not used by any quantization path of the reference (nothing outside this group calls them); kept so
+# that the module surface is complete.  Plain torch ops on whatever device the input lives on.
+def invert_pytorch_vector(pytorch_vector):
+    """The 1-D vector reversed (ref: :8-14)."""
+    return torch.flip(pytorch_vector, dims=[0])
+
+
+def findFirstNonZeroIndex(pytorch_vector):
+    """Index of the first non-zero entry, -1 if there is none (ref: :16-24)."""
+    nz = torch.nonzero(pytorch_vector.reshape(-1) != 0)
+    return int(nz[0]) if nz.numel() else -1
+
+
+def cart2hyperspherical(cartesianCoordinates):
+    """(radius, angles[n-1]) of an n-vector (ref: :27-52).  With tail[i] = sqrt(sum_{j>=i} x_j^2):
+    angle_i = acos(x_i / tail[i]), 0 where the whole tail is zero, and the last angle is reflected
+    to (pi, 2 pi) when the last coordinate is negative."""
+    x = cartesianCoordinates
+    n = x.size(0)
+    tail = torch.flip(torch.sqrt(torch.flip(x ** 2, dims=[0]).cumsum(dim=0)), dims=[0])     # tail[i], i = 0..n-1
+    radius = tail[0]
+    head, norm = x[:n - 1], tail[:n - 1]
+    live = norm != 0
+    angles = torch.where(live, torch.acos(head / torch.where(live, norm, torch.ones_like(norm))), torch.zeros_like(head))
+    if n > 1 and bool(x[-1] < 0):
+        angles[-1] = 2 * math.pi - angles[-1]
+    return radius, angles
+
+
+def hypershperical2cart(sphericalCoordinates):
+    """Inverse of cart2hyperspherical (ref: :54-64; the reference's spelling of the name is kept)."""
+    radius, angles = sphericalCoordinates[0], sphericalCoordinates[1]
+    one = torch.ones(1, dtype=angles.dtype, device=angles.device)
+    cos = torch.cat((torch.cos(angles), one))
+    sin_prod = torch.cat((one, torch.sin(angles).cumprod(dim=0)))
+    return radius * sin_prod * cos
+
+
 def create_bucket_tensor(tensor, bucket_size, fill_values='last'):
     """View `tensor` as rows of `bucket_size` elements, padding a ragged tail with copies of the
     last element (or NaN).  ref: help_functions.py:67-94.  The kernels never materialise this

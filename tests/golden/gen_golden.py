@@ -21,6 +21,7 @@ Outputs (all small, committed):
   nonfinite.npz    uniformQuantization on inputs holding NaN / +-inf
   misc.npz         scale_down / inv_scale_down round trips, initialize_quantization_points,
                    assign_bits_automatically, huffman mean bit length
+  coords.npz       cart2hyperspherical / hypershperical2cart / invert_pytorch_vector / findFirstNonZeroIndex
   big_checksums.json   float64 checksums / histograms of larger runs (no tensors stored)
 """
 import inspect
@@ -410,6 +411,31 @@ def run_nonfinite():
     print('nonfinite cases:', len(meta))
 
 
+def run_coords():
+    """The hyperspherical-coordinate helpers of help_functions.py:8-64 (not on the quantization path; kept
+    for a complete module surface).  Vectors with trailing zeros, a single non-zero head, all zeros, a
+    negative last coordinate."""
+    out = {}
+    cases = []
+    g = gen(11)
+    vecs = [torch.randn(5, generator=g), torch.randn(2, generator=g), torch.randn(33, generator=g),
+            torch.tensor([0.3, -1.2, 0.0, 0.0]), torch.tensor([-2.0, 0.0, 0.0]), torch.tensor([1.5, 0.0]),
+            torch.zeros(4), torch.tensor([0.5, 0.25, -0.75]), torch.tensor([0.0, 0.0, 2.0]),
+            torch.tensor([0.0, -3.0, 0.0, 0.0, 0.0])]
+    for i, v in enumerate(vecs):
+        r, ang = refqhf.cart2hyperspherical(v.clone())
+        back = refqhf.hypershperical2cart((r, ang))
+        out['c%d_x' % i] = v.numpy()
+        out['c%d_r' % i] = np.asarray(float(r), dtype=np.float32)
+        out['c%d_ang' % i] = ang.numpy()
+        out['c%d_back' % i] = back.numpy()
+        out['c%d_inv' % i] = refqhf.invert_pytorch_vector(v).numpy()
+        cases.append({'first_nonzero': int(refqhf.findFirstNonZeroIndex(v))})
+    out['meta'] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(HERE, 'coords.npz'), **out)
+    print('coords cases:', len(cases))
+
+
 def run_big():
     """Checksums of larger runs; inputs are re-creatable from the seed with torch.randn (CPU
     generator streams are identical for the same torch build), and are also re-derivable through
@@ -446,4 +472,5 @@ if __name__ == '__main__':
     run_misc()
     run_nonuniform_options()
     run_nonfinite()
+    run_coords()
     run_big()

@@ -144,3 +144,19 @@ def test_checkpoint_formats_roundtrip(tmp_path):
     checkpoints.save_training_run(run, net, {'numBits': 4, 'bucket_size': 256}, {'lossSaved': [1.0]})
     sd2, args, info2 = checkpoints.load_training_run(run)
     assert args['numBits'] == 4 and info2['lossSaved'] == [1.0] and set(sd2) == set(net.state_dict())
+
+
+def test_hyperspherical_helpers_match_reference():
+    """help_functions.py:8-64 (off the quantization path): outputs of the reference itself, tests/golden/coords.npz."""
+    from conftest import load_golden
+    import quantization.help_functions as hf
+    G = load_golden('coords.npz')
+    for i, c in enumerate(G.meta):
+        x = torch.from_numpy(G.z['c%d_x' % i])
+        r, ang = hf.cart2hyperspherical(x.clone())
+        assert np.allclose(float(r), float(G.z['c%d_r' % i]), rtol=1e-6, atol=0)
+        assert np.allclose(ang.numpy(), G.z['c%d_ang' % i], rtol=1e-6, atol=1e-7), i
+        back = hf.hypershperical2cart((r, ang))
+        assert np.allclose(back.numpy(), G.z['c%d_back' % i], rtol=1e-5, atol=1e-6), i
+        assert np.array_equal(hf.invert_pytorch_vector(x).numpy(), G.z['c%d_inv' % i])
+        assert hf.findFirstNonZeroIndex(x) == c['first_nonzero']
