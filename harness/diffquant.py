@@ -27,7 +27,12 @@ from . import models
 
 class DiffQuantTrainer(object):
     def __init__(self, model, device, num_points=4, bucket_size=256, lr=1e-5, momentum=0.9, nesterov=True,
-                 quantize_first_and_last_layer=True, mode='per_tensor'):
+                 quantize_first_and_last_layer=True, mode='per_tensor', assign_bits_automatically=False,
+                 estimate_batches=None):
+        """num_points: one count for every tensor.  With assign_bits_automatically the counts are spread over
+        the tensors by the 2-norm of their gradients under the plain cross-entropy loss on `estimate_batches`
+        (the reference uses 5 mini-batches; ref: :424-448, help_functions.py:97-138), so tensors end up with
+        different numbers of points."""
         self.device = device
         self.teacher = model.to(device).eval()                       # ref: :496 modelToQuantize.eval()
         for p in self.teacher.parameters():
@@ -40,15 +45,21 @@ class DiffQuantTrainer(object):
         n = len(params)
         self.slots = [i for i in range(n) if quantize_first_and_last_layer or (i != 0 and i != n - 1)]
         self.params = params
-        self.k = num_points
+        self.counts = [int(num_points)] * len(self.slots)
+        if assign_bits_automatically:
+            self.counts = self._assign_counts(estimate_batches, self.counts)
+        self.k = max(self.counts)
         scaling = quantization.ScalingFunction('linear', False, False, bucket_size, False)     # ref: :421
-        # all points live in ONE [ntensors, k] tensor: one optimizer state, one all-reduce
-        self.points = torch.empty(len(self.slots), num_points, device=device)
+        # all points live in ONE [ntensors, k] tensor: one optimizer state, one all-reduce.  Rows of tensors
+        # with fewer than k points are padded with +inf: a point at +inf is never the nearest one (its
+        # midpoint is +inf or NaN, never <= u), so it receives no weight and a zero gradient, SGD leaves it
+        # where it is (inf - lr * 0) and the per-step sort keeps it at the end of the row.
+        self.points = torch.full((len(self.slots), self.k), float('inf'), device=device)
         self.points_grad = torch.zeros_like(self.points)
         self.fns = []
         for row, i in enumerate(self.slots):
             w = params[i].data
-            self.points[row] = qhf.initialize_quantization_points(w, scaling, num_points)      # ref: :460-462
+            self.points[row, :self.counts[row]] = qhf.initialize_quantization_points(w, scaling, self.counts[row])   # ref: :460-462
             self.fns.append(quantization.nonUniformQuantization_variable(
                 bucket_size=bucket_size, pre_process_tensors=True, tensor=w))                  # ref: :507-509
         self.points.grad = self.points_grad
@@ -65,17 +76,28 @@ class DiffQuantTrainer(object):
             for row, i in enumerate(self.slots):
                 params[i].data = qs[row]
                 params[i].grad = gs[row]
-            self.mt = MultiTensorDiffQuant([self.teacher_params[i] for i in self.slots], qs, gs, num_points, bucket_size)
+            self.mt = MultiTensorDiffQuant([self.teacher_params[i] for i in self.slots], qs, gs, self.k, bucket_size)
         opts = dict(momentum=momentum, nesterov=nesterov) if momentum != 0 else {}
         self.opt = torch.optim.SGD([self.points], lr=lr, **opts)                                # ref: :482-484
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _assign_counts(self, batches, counts):
+        """Gradient 2-norms under the plain loss -> points per tensor (ref: conv_forward_model.py:424-448)."""
+        if not batches:
+            raise ValueError('assign_bits_automatically needs estimate_batches (the reference uses 5 mini-batches)')
+        self.student.zero_grad()
+        for images, labels in batches:                                                          # ref: :427-431
+            torch.nn.functional.cross_entropy(self.student(images), labels).backward()
+        norms = torch.stack([(self.params[i].grad / len(batches)).norm() for i in self.slots]).tolist()   # ref: :434-439
+        self.student.zero_grad(set_to_none=True)                                                # ref: :442
+        return [int(c) for c in qhf.assign_bits_automatically(norms, counts, input_is_point=True)]   # ref: :446-448
 
     def quantize(self):
         if self.mode == 'multi':
             self.mt.forward(self.points)                 # one launch: every tensor's weights re-assigned in place
             return
         for row, i in enumerate(self.slots):                                                    # ref: :524-532
-            self.params[i].data = self.fns[row].forward(None, self.points[row])
+            self.params[i].data = self.fns[row].forward(None, self.points[row, :self.counts[row]].contiguous())
 
     def forward_backward(self, images, labels):
         if self.mode == 'multi':
@@ -98,7 +120,7 @@ class DiffQuantTrainer(object):
             self.mt.backward(out=self.points_grad)       # one launch (+ one fold) for all tensors
             return
         for row, i in enumerate(self.slots):                                                    # ref: :538-545
-            self.points_grad[row] = self.fns[row].backward(self.params[i].grad)[1]
+            self.points_grad[row, :self.counts[row]] = self.fns[row].backward(self.params[i].grad)[1]
 
     def step(self, images, labels):
         self.quantize()

@@ -141,3 +141,36 @@ def test_multi_tensor_diffquant_equals_per_tensor():
         la, lb = a.step(xs, ys), b.step(xs, ys)
         assert abs(float(la) - float(lb)) <= 1e-4 * max(1.0, abs(float(la)))
     assert torch.allclose(a.points, b.points, rtol=1e-3, atol=1e-4)      # same trajectory up to fp32 summation order
+
+
+def test_diffquant_automatic_point_counts():
+    """assignBitsAutomatically (ref: conv_forward_model.py:424-448): gradient norms -> a different number of
+    points per tensor.  The multi-tensor path carries them as +inf-padded rows of one [ntensors, kmax] tensor:
+    same weights, indices and point gradients as the per-tensor calls with the true counts; padding stays put."""
+    from harness.diffquant import DiffQuantTrainer
+    est = [synthetic_batch(16, DEV, seed=100 + j) for j in range(5)]
+    torch.manual_seed(0)
+    a = DiffQuantTrainer(models.student(), DEV, num_points=8, bucket_size=256, lr=1e-2, mode='per_tensor',
+                         assign_bits_automatically=True, estimate_batches=est)
+    torch.manual_seed(0)
+    b = DiffQuantTrainer(models.student(), DEV, num_points=8, bucket_size=256, lr=1e-2, mode='multi',
+                         assign_bits_automatically=True, estimate_batches=est)
+    assert a.counts == b.counts and sum(a.counts) == 8 * len(a.slots)
+    assert len(set(a.counts)) > 1 and min(a.counts) >= 4                  # redistributed, floor = half the input
+    assert torch.equal(a.points, b.points)
+    pad = torch.isinf(b.points)
+    assert int(pad.sum()) == sum(b.k - c for c in b.counts)
+    x, y = synthetic_batch(16, DEV, seed=5)
+    a.quantize(); b.quantize()
+    for pa, pb in zip(a.params, b.params):
+        assert torch.equal(pa.data, pb.data) and bool(torch.isfinite(pb.data).all())
+    a.forward_backward(x, y); b.forward_backward(x, y)
+    a.point_gradients(); b.point_gradients()
+    scale = a.points_grad.abs().max()
+    assert torch.allclose(a.points_grad, b.points_grad, rtol=1e-4, atol=float(scale) * 1e-5)
+    assert bool((b.points_grad[pad] == 0).all())
+    for step in range(2):
+        xs, ys = synthetic_batch(16, DEV, seed=40 + step)
+        la, lb = a.step(xs, ys), b.step(xs, ys)
+        assert bool(torch.isfinite(lb)) and abs(float(la) - float(lb)) < 1e-3 * max(1.0, abs(float(la)))
+    assert torch.equal(torch.isinf(b.points), pad) and torch.equal(torch.isinf(a.points), pad)
