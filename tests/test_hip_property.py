@@ -121,3 +121,56 @@ def test_ste_backward_matches_oracle(n, bucket, s, seed, kind):
     assert not np.any((out != g) & ~allowed[:n])
     visible = np.abs(ref - g) > 4 * atol + 4 * np.spacing(np.abs(g))
     assert np.all((out != g)[visible])
+
+
+@settings(max_examples=25 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
+@given(sizes_=st.lists(st.one_of(st.integers(1, 300), st.integers(300, 70000)), min_size=1, max_size=12),
+       bucket=st.sampled_from([None, 256, 256, 64, 128, 100, 7, 1024]), s=st.sampled_from([2, 4, 16, 256]),
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 5), misalign=st.booleans())
+def test_multi_tensor_matches_oracle(sizes_, bucket, s, seed, kind, misalign):
+    """One launch over a random set of tensors (carved out of one flat buffer, optionally at odd element
+    offsets so that some bases are not 16-byte aligned) == the oracle on each tensor."""
+    from quantized_distillation_amd.multi_tensor import MultiTensorQuantizer
+    xs = [make(n, seed + 13 * i, (kind + i) % 6) for i, n in enumerate(sizes_)]
+    gap = 3 if misalign else 0
+    total = sum(n + gap for n in sizes_)
+    flat_in = torch.zeros(total, device=DEV)
+    flat_out = torch.full((total,), 777.0, device=DEV)
+    ins, outs, off = [], [], 0
+    for x in xs:
+        off += gap
+        ins.append(flat_in[off:off + x.size]); outs.append(flat_out[off:off + x.size])
+        ins[-1].copy_(torch.from_numpy(x))
+        off += x.size
+    mt = MultiTensorQuantizer(ins, s, bucket, outputs=outs)
+    mt.quantize()
+    for x, o in zip(xs, outs):
+        r = oc.uniform_quantize(x, s, bucket, want_idx=False, want_lev=False)
+        assert np.array_equal(o.cpu().numpy(), r['q'])
+    if gap:                                                            # nothing written between the tensors
+        keep = torch.ones(total, dtype=torch.bool)
+        off = 0
+        for x in xs:
+            off += gap
+            keep[off:off + x.size] = False
+            off += x.size
+        assert bool((flat_out.cpu()[keep] == 777.0).all())
+
+
+@settings(max_examples=25 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=sizes, bucket=buckets, s=levels, seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 2),
+       clamp=st.sampled_from([False, 0.5, 2.0]))
+def test_uniform_subtract_mean_matches_oracle(n, bucket, s, seed, kind, clamp):
+    """subtract_mean=True: the mean is a float64-accumulated device reduction (qd_mean_f32); the oracle is given
+    the device's mean so that the comparison of everything downstream stays bit-exact, and the mean itself
+    is checked against numpy's float64 mean to 1 ulp-ish."""
+    x = make(n, seed, kind)
+    xd = torch.from_numpy(x).to(DEV)
+    q, sf = quantization.uniformQuantization(xd, s, bucket_size=bucket, subtract_mean=True, max_element=clamp)
+    mean = float(sf.mean_tensor)
+    ref_mean = float(np.float32(x.astype(np.float64).mean()))
+    assert abs(mean - ref_mean) <= 2e-7 * max(1.0, abs(ref_mean))
+    r = oc.uniform_quantize(x, s, bucket, max_element=clamp, subtract_mean=True, mean=mean, want_idx=False, want_lev=False)
+    assert np.array_equal(q.cpu().numpy(), r['q'])
+    assert np.array_equal(sf.alpha.cpu().numpy().reshape(-1), r['alpha'])
+    assert np.array_equal(sf.beta.cpu().numpy().reshape(-1), r['beta'])
