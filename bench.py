@@ -406,7 +406,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, event_ms = float(t[0]), float(t[1])
 
-    # copy ceiling on this very GPU: torch's own device-to-device copy of the same 256 MiB tensors
+    # reference point on this very GPU: torch's own device-to-device copy of the same 256 MiB tensors
     ya = torch.empty_like(xs[0])
     for _ in range(3):
         ya.copy_(xs[1])
@@ -468,7 +468,7 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': load_pmc_traffic(),
                 'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
                 'timing': 'HIP events on the launch stream around the %d timed launches (includes inter-launch gaps)' % args.steps,
-                'copy_ceiling_GBps': round(copy_gbps, 1),
+                'torch_d2d_copy_GBps': round(copy_gbps, 1),      # torch's own copy of the same bytes, same box (a hand-written NT copy reaches 6.3-6.5 TB/s: profiles/r01_kbench.txt)
             },
             'cpu_baseline': cpu,
             'distill': distill,
