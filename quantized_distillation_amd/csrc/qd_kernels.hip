@@ -515,6 +515,133 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     }
 }
 
+// ---- chunk path: bucket sizes that are a multiple of 4 but not one of the vector sizes ----------
+// (100, 1000, 36, 4096, ...).  A wave streams a CHUNK of m consecutive buckets (m a power of two, m * row / 4
+// <= VMAX * 64 float4) with fully coalesced 16-byte loads -- lane i holds float4 i, i + 64, ... of the chunk,
+// whatever the bucket boundaries are -- and keeps it in registers: one pass over HBM.  The per-float4 (min,
+// max) go through LDS, where lane groups of 64 / m lanes reduce one bucket each; (alpha, beta) of the chunk's
+// buckets come back through an LDS table.  Every chunk starts at a multiple of row * 4 bytes, so alignment
+// only needs row % 4 == 0.  The buckets after the last whole chunk are done by the last block, a DPP row each.
+template <int MODE, int VMAX>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4)))   // the chunk lives in registers
+void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
+    __shared__ PointTable Ts;
+    const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: pairs[VMAX * 64], ab[256]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float2* pr = chunk_lds + w * (VMAX * 64 + 256);
+    float2* ab = pr + VMAX * 64;
+
+    const int Bq = (int)(p.row >> 2);                  // float4 per bucket
+    const int nf = m * Bq;                             // float4 per chunk
+    const int nj = (nf + 63) >> 6;                     // rounds of 64 float4 (<= VMAX)
+    const int mlanes = m < 64 ? m : 64;                // buckets reduced side by side
+    const int G = 64 / mlanes;                         // lanes per bucket in the reduce step (power of two)
+    const int bl = lane / G, sub = lane % G;
+    const int step_q = 64 / Bq, step_r = 64 % Bq;      // bucket of float4 (lane + 64 j): advanced incrementally
+    const int q0 = lane / Bq, r0 = lane % Bq;
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+    const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    const int64_t wave = uniform_wave_index();
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+
+    for (int64_t c = wave; c < nchunks; c += nwaves) {
+        const int64_t b0 = c * m;                      // first bucket of the chunk
+        const int64_t e0 = b0 * p.row;                 // first element
+        const f4* src = (const f4*)(p.x + e0);
+        f4 v[VMAX];
+        // always VMAX loads, the address clamped to the chunk's last float4 (a broadcast re-load): a load behind
+        // a branch -- even a wave-uniform one -- gets an s_waitcnt vmcnt(0) at the join and the chunk would be
+        // fetched one memory round trip per float4.  The launcher picks VMAX in {8, 16, 32} to bound the waste.
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {
+            const int f = lane + 64 * j;
+            v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);             // all loads in flight before the first use
+        if (!prescaled) {
+#pragma unroll
+            for (int j = 0; j < VMAX; ++j) {
+                const int f = lane + 64 * j;
+                if (j < nj && f < nf) {
+                    v[j] = prep4(v[j], pp);
+                    float mn = fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w));
+                    const float mx = fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w));
+                    if (has_nan4(v[j])) mn = NAN;      // carried as a NaN minimum (v_min would drop it)
+                    pr[f] = make_float2(mn, mx);
+                }
+            }
+            // LDS operations of one wave complete in order; the fence/barrier only stop compiler reordering
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int bb = bl; bb < m; bb += mlanes) {  // uniform trip count: m is a multiple of mlanes
+                const float2* q = pr + bb * Bq;
+                float mn = INFINITY, mx = -INFINITY;
+                int nan = 0;
+                for (int t = sub; t < Bq; t += G) {
+                    const float2 pm = q[t];
+                    nan |= (pm.x != pm.x);
+                    mn = fminf(mn, pm.x); mx = fmaxf(mx, pm.y);
+                }
+                for (int sft = 1; sft < G; sft <<= 1) {
+                    mn = fminf(mn, __shfl_xor(mn, sft));
+                    mx = fmaxf(mx, __shfl_xor(mx, sft));
+                    nan |= __shfl_xor(nan, sft);
+                }
+                if (nan) { mn = NAN; mx = NAN; }
+                float a, b;
+                alpha_beta(mn, mx, a, b);
+                if (sub == 0) {
+                    ab[bb] = make_float2(a, b);
+                    if (p.alpha) p.alpha[b0 + bb] = a;
+                    if (p.beta) p.beta[b0 + bb] = b;
+                }
+            }
+        } else {
+            for (int bb = lane; bb < m; bb += 64) ab[bb] = make_float2(p.alpha[b0 + bb], p.beta[b0 + bb]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f4* dst = (f4*)(p.out + e0);
+        int q = q0, r = r0;
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {
+            const int f = lane + 64 * j;
+            if (j < nj && f < nf) {
+                const float2 s = ab[q];
+                const int64_t e = e0 + ((int64_t)f << 2);
+                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                float side[4];
+                f4 o;
+                o.x = transform<MODE>(p, T, v[j].x, s.x, s.y, pp.mean, rnd[0], side[0]);
+                o.y = transform<MODE>(p, T, v[j].y, s.x, s.y, pp.mean, rnd[1], side[1]);
+                o.z = transform<MODE>(p, T, v[j].z, s.x, s.y, pp.mean, rnd[2], side[2]);
+                o.w = transform<MODE>(p, T, v[j].w, s.x, s.y, pp.mean, rnd[3], side[3]);
+                __builtin_nontemporal_store(o, dst + f);
+                store_side4<MODE>(p, e, side);
+            }
+            q += step_q; r += step_r;
+            if (r >= Bq) { r -= Bq; ++q; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next chunk overwrites pr / ab
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (blockIdx.x == gridDim.x - 1) {                 // buckets after the last whole chunk (incl. the ragged one)
+        const int row_id = threadIdx.x >> 4;
+        for (int64_t bkt = nchunks * m + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
+            const int64_t lo = bkt * p.row;
+            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+            if (hi - lo == p.row) bucket_lanes4<MODE, 16>(p, T, bkt, lo, threadIdx.x & 15, pp);   // full: float4 accesses
+            else bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
+        }
+    }
+}
+
 // ---- generic path, small/medium rows: one lane group (16 lanes or a wave) per bucket, 256-thread
 // blocks, no LDS, no barrier.  Any row length / alignment.
 template <int MODE, int LANES>
@@ -1387,6 +1514,23 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     }
 #undef QD_VEC
     p.nvec = 0;
+    // float4 per lane a chunk holds.  Measured at 64 Mi elements, bucket 100 / 36 / 300 / 1000 / 2000 (the one-bucket-
+    // per-lane-group kernels below: 145 / 211 / 167 / 114 / 122 us): 16 -> 123 / 123 / 128 / 122 / 120 us (195 VGPRs,
+    // two waves per SIMD: the load and the compute phase of a wave do not overlap); 8 -> 100 / 100 / 103 / 108 / 108;
+    // 4 -> 124 / 131 / 130 / 118 / 121.  Bucket 12 / 4: 101 / 112 us instead of 571 / 1616.
+    constexpr int kChunkV = 8;
+    if (aligned && p.nb > 1 && (p.row & 3) == 0 && p.row <= (int64_t)kChunkV * 256) {
+        const int64_t bq = p.row >> 2;
+        int m = 256;
+        while (m > 1 && (int64_t)m * bq > kChunkV * 64) m >>= 1;
+        const int64_t nchunks = nfull / m;
+        if (nchunks > 0) {
+            const size_t lds = (size_t)2 * (kChunkV * 64 + 256) * sizeof(float2);       // two waves per block
+            const int blocks = blocks_for(nchunks, 2) + 1;                             // +1: the block that owns the tail
+            hipLaunchKernelGGL((k_bucket_chunk<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
+            return check_launch();
+        }
+    }
     if (p.row <= 256) {                                  // 16 buckets per block, a DPP row each
         hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16)), dim3(256), 0, st, p);
     } else if (p.row <= 16384) {                         // 4 buckets per block, one wave each
