@@ -443,6 +443,13 @@ def main():
         if n_gpus == 4 or os.environ.get('QD_BENCH_CFG5') == '1':
             distill['nmt_lstm_dp'] = dp_config_steps_per_sec('nmt', dev, rank, n_gpus, distributed)
 
+    # RCCL writes a version banner to the C-level stdout, which is block-buffered when piped and would
+    # otherwise be flushed at exit, i.e. after the JSON line: push it out now on every rank, so that the JSON
+    # is the last thing on stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if distributed:
+        dist.barrier()
     if rank == 0:
         bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM
         total_bytes = bytes_per_launch * args.steps * n_gpus
@@ -475,7 +482,7 @@ def main():
             'parity_bit_exact_vs_oracle': parity,
             'device': torch.cuda.get_device_name(dev),
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
