@@ -642,6 +642,124 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
     }
 }
 
+// Same for bucket sizes that are NOT a multiple of 4 (33, 50, 7, ... >= 4): m is a multiple of 4, so every chunk
+// still starts 16-byte aligned and holds a whole number of float4, but a float4 may straddle two buckets (never
+// three: row >= 4).  The prepared values themselves go through LDS (16 B per float4), the reduce step reads its
+// bucket element by element, and the transform picks (alpha, beta) per element from the two candidate buckets.
+template <int MODE, int VMAX>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4)))
+void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
+    __shared__ PointTable Ts;
+    const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: vals[VMAX * 256] floats, ab[256]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* vals = (float*)(chunk_lds + w * (VMAX * 128 + 256));
+    float2* ab = (float2*)(vals + VMAX * 256);
+
+    const int B = (int)p.row;
+    const int nf = (m * B) >> 2;                       // float4 per chunk (m % 4 == 0)
+    const int nj = (nf + 63) >> 6;
+    const int mlanes = m < 64 ? m : 64;
+    const int G = 64 / mlanes;
+    const int bl = lane / G, sub = lane % G;
+    const int step_q = 256 / B, step_r = 256 % B;      // bucket / offset of element 4 (lane + 64 j), advanced incrementally
+    const int q0 = (4 * lane) / B, r0 = (4 * lane) % B;
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+    const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    const int64_t wave = uniform_wave_index();
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+
+    for (int64_t c = wave; c < nchunks; c += nwaves) {
+        const int64_t b0 = c * m;
+        const int64_t e0 = b0 * p.row;
+        const f4* src = (const f4*)(p.x + e0);
+        f4 v[VMAX];
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {               // always-issued loads with a clamped address, as above
+            const int f = lane + 64 * j;
+            v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!prescaled) {
+#pragma unroll
+            for (int j = 0; j < VMAX; ++j) {
+                const int f = lane + 64 * j;
+                if (j < nj && f < nf) {
+                    v[j] = prep4(v[j], pp);
+                    ((f4*)vals)[f] = v[j];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int bb = bl; bb < m; bb += mlanes) {
+                const float* q = vals + bb * B;
+                float mn = INFINITY, mx = -INFINITY;
+                int nan = 0;
+                for (int t = sub; t < B; t += G) {
+                    const float x = q[t];
+                    nan |= (x != x);
+                    mn = fminf(mn, x); mx = fmaxf(mx, x);
+                }
+                for (int sft = 1; sft < G; sft <<= 1) {
+                    mn = fminf(mn, __shfl_xor(mn, sft));
+                    mx = fmaxf(mx, __shfl_xor(mx, sft));
+                    nan |= __shfl_xor(nan, sft);
+                }
+                if (nan) { mn = NAN; mx = NAN; }
+                float a, b;
+                alpha_beta(mn, mx, a, b);
+                if (sub == 0) {
+                    ab[bb] = make_float2(a, b);
+                    if (p.alpha) p.alpha[b0 + bb] = a;
+                    if (p.beta) p.beta[b0 + bb] = b;
+                }
+            }
+        } else {
+            for (int bb = lane; bb < m; bb += 64) ab[bb] = make_float2(p.alpha[b0 + bb], p.beta[b0 + bb]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f4* dst = (f4*)(p.out + e0);
+        int q = q0, r = r0;
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {
+            const int f = lane + 64 * j;
+            if (j < nj && f < nf) {
+                const float2 s0 = ab[q];
+                const float2 s1 = ab[q + 1 < m ? q + 1 : q];
+                const int cut = B - r;                  // elements c >= cut of this float4 belong to bucket q + 1
+                const int64_t e = e0 + ((int64_t)f << 2);
+                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                float side[4];
+                f4 o;
+                o.x = transform<MODE>(p, T, v[j].x, s0.x, s0.y, pp.mean, rnd[0], side[0]);
+                o.y = transform<MODE>(p, T, v[j].y, 1 >= cut ? s1.x : s0.x, 1 >= cut ? s1.y : s0.y, pp.mean, rnd[1], side[1]);
+                o.z = transform<MODE>(p, T, v[j].z, 2 >= cut ? s1.x : s0.x, 2 >= cut ? s1.y : s0.y, pp.mean, rnd[2], side[2]);
+                o.w = transform<MODE>(p, T, v[j].w, 3 >= cut ? s1.x : s0.x, 3 >= cut ? s1.y : s0.y, pp.mean, rnd[3], side[3]);
+                __builtin_nontemporal_store(o, dst + f);
+                store_side4<MODE>(p, e, side);
+            }
+            q += step_q; r += step_r;
+            if (r >= B) { r -= B; ++q; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (blockIdx.x == gridDim.x - 1) {
+        const int row_id = threadIdx.x >> 4;
+        for (int64_t bkt = nchunks * m + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
+            const int64_t lo = bkt * p.row;
+            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+            bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
+        }
+    }
+}
+
 // ---- generic path, small/medium rows: one lane group (16 lanes or a wave) per bucket, 256-thread
 // blocks, no LDS, no barrier.  Any row length / alignment.
 template <int MODE, int LANES>
@@ -1528,6 +1646,17 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             const size_t lds = (size_t)2 * (kChunkV * 64 + 256) * sizeof(float2);       // two waves per block
             const int blocks = blocks_for(nchunks, 2) + 1;                             // +1: the block that owns the tail
             hipLaunchKernelGGL((k_bucket_chunk<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
+            return check_launch();
+        }
+    }
+    if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row >= 4 && p.row * 4 <= (int64_t)kChunkV * 256) {
+        int m = 256;                                         // a multiple of 4: chunks start 16-byte aligned
+        while (m > 4 && (int64_t)m * p.row > kChunkV * 256) m >>= 1;
+        const int64_t nchunks = nfull / m;
+        if (nchunks > 0) {
+            const size_t lds = (size_t)2 * (kChunkV * 128 + 256) * sizeof(float2);
+            const int blocks = blocks_for(nchunks, 2) + 1;
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
             return check_launch();
         }
     }
