@@ -129,6 +129,30 @@ def uniform_quantize_stochastic(x, s, rand, bucket=None, max_element=False, subt
     return out
 
 
+def philox4x32_7_uniform(seed, n):
+    """The uniform [0,1) draw of every element index 0..n-1 under the in-kernel generator of the HIP path
+    (quantized_distillation_amd/csrc/qd_common.h: philox_uniform4) -- Philox4x32 with 7 rounds, counter =
+    (element >> 2, 0x51ed270b, 0x2545f491), key = the 64-bit seed, component = element & 3, 24 mantissa bits.
+    This restates OUR generator (the reference draws torch.rand on the host, quant_functions.py:185-186, which
+    no device generator can reproduce); it lets the stochastic branch be checked bit for bit on every kernel
+    path instead of only statistically."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    blocks = np.arange((n + 3) // 4, dtype=np.uint64)
+    c0, c1 = blocks & mask, blocks >> np.uint64(32)
+    c2 = np.full_like(blocks, 0x51ed270b)
+    c3 = np.full_like(blocks, 0x2545f491)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(7):
+        p0, p1 = M0 * c0, M1 * c2                                   # 32 x 32 -> 64-bit products
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    words = np.stack([c0, c1, c2, c3], axis=1).reshape(-1)[:n]
+    return ((words >> np.uint64(8)).astype(np.float32) * F32(1.0 / 16777216.0)).astype(F32)
+
+
 # ----------------------------------------------------------------------------- non-uniform
 def assign_distance(u, pts):
     """Nearest sorted point, ties to the UPPER point.  ref: quant_functions.py:267-273."""

@@ -213,6 +213,28 @@ def test_stochastic_rounding_statistics():
     assert abs((host(qb).astype(np.float64) - xh).mean()) < 3e-4
 
 
+def test_stochastic_rounding_bit_exact_on_every_kernel_path():
+    """The stochastic branch is defined by (seed, element index) only, so every kernel path -- vector, chunk,
+    chunk_any, lane-group, block-per-bucket, single bucket -- must produce the same bits as the oracle's
+    restatement of the reference formula (quant_functions.py:174-187) fed with the generator's draws."""
+    import quantization.quant_functions as qf
+    rng = np.random.RandomState(11)
+    cases = [(10007, 256, 16), (10007, 64, 4), (10007, 100, 16), (10007, 33, 4), (10007, 7, 16), (10007, 1000, 4),
+             (70001, 2048, 16), (70001, 4096, 4), (70001, 20000, 16), (10007, None, 16), (300001, None, 4),
+             (10007, 3, 4), (10007, 513, 16), (4096, 128, 2), (50, 256, 16)]
+    for n, bucket, s in cases:
+        x = rng.randn(n).astype(np.float32)
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + qf._STOCHASTIC_CALLS[0] + 1) & 0xFFFFFFFFFFFFFFFF
+        q, sf = quantization.uniformQuantization(dev(x), s, stochastic_rounding=True, bucket_size=bucket)
+        draws = onp.philox4x32_7_uniform(seed, n)
+        nb, row, padded = onp.bucket_geometry(n, bucket)
+        rand = np.zeros(padded, np.float32)
+        rand[:n] = draws
+        want = onp.uniform_quantize_stochastic(x, s, rand, bucket)
+        assert np.array_equal(host(q), want['q']), (n, bucket, s)
+        assert np.array_equal(host(sf.alpha).reshape(-1), want['alpha'].reshape(-1)), (n, bucket, s)
+
+
 # ------------------------------------------------------------------------------ non-uniform (K4/K5/K6)
 def test_nonuniform_golden(golden_nonuniform):
     G = golden_nonuniform
