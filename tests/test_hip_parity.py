@@ -604,3 +604,42 @@ def test_nonuniform_options_golden(golden_nonuniform_options):
         else:
             assert np.array_equal(host(idx), G.arr('o', i, 'idx')) and np.array_equal(host(q), G.arr('o', i, 'q')), (i, c)
             assert np.array_equal(host(ip), G.arr('o', i, 'idx_pre')) and np.array_equal(host(qp), G.arr('o', i, 'q_pre')), (i, c)
+
+
+def test_api_calls_under_hipgraph_capture():
+    """Every entry point enqueues on the current stream and allocates only through torch, so the drop-in calls
+    can be captured in a hipGraph (torch.cuda.CUDAGraph) and replayed on new data in the static input buffers."""
+    rng = np.random.RandomState(21)
+    n, k = 100003, 16
+    x0, x1 = rng.randn(n).astype(np.float32), (rng.randn(n) * 3 + 1).astype(np.float32)
+    g0, g1 = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    pts = np.sort(rng.rand(k)).astype(np.float32)
+    xs, gs, pd = dev(x0), dev(g0), dev(pts)
+    fn = quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=dev(x0))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                  # warm-up outside the capture (lazy allocations)
+        quantization.uniformQuantization(xs, 16, bucket_size=256)
+        quantization.uniformQuantization(xs, 16)
+        quantization.nonUniformQuantization(xs, pd, bucket_size=256)
+        fn.forward(None, pd); fn.backward(gs)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        qb, sfb = quantization.uniformQuantization(xs, 16, bucket_size=256)
+        qg, _ = quantization.uniformQuantization(xs, 16)
+        qn, idx, _ = quantization.nonUniformQuantization(xs, pd, bucket_size=256)
+        fn.forward(None, pd)
+        _, gp = fn.backward(gs)
+    for xv, gv in ((x1, g1), (x0, g0)):
+        xs.copy_(dev(xv)); gs.copy_(dev(gv))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(host(qb), oc.uniform_quantize(xv, 16, 256, want_idx=False, want_lev=False)['q'])
+        assert np.array_equal(host(qg), oc.uniform_quantize(xv, 16, None, want_idx=False, want_lev=False)['q'])
+        r = oc.nonuniform_quantize(xv, pts, 256, 'distance')
+        assert np.array_equal(host(idx), r['idx']) and np.array_equal(host(qn), r['q'])
+        rm = oc.nonuniform_quantize(x0, pts, 256, 'midpoint')     # fn was pre-processed on x0: its u is resident
+        want, absum = oc.point_grad(gv, rm['idx'], rm['alpha'], 256, k)
+        assert np.all(np.abs(host(gp).astype(np.float64) - want) <= 4e-6 * absum + 1e-30)
