@@ -1627,6 +1627,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             case 512: QD_VEC(64, 2, 2)
             case 1024: QD_VEC(64, 4, 1)
             case 2048: QD_VEC(64, 8, 1)
+            case 4096: QD_VEC(64, 16, 1)
             default: break;
         }
     }
