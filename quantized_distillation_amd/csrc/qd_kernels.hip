@@ -1845,7 +1845,11 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     // partial rows of k floats each must fit the workspace's [kPartialBlocks * kMaxPoints] floats
     int blocks = blocks_for(n, 256 * 4 * 2);
     const int64_t max_rows = (int64_t)kPartialBlocks * kMaxPoints / k;
-    const int64_t cap = 2048;     // partial rows the fold kernel has to read: 8192 rows cost it 9.5 us, 2048 rows ~3 us
+    // Grid: measured at 64 Mi elements, k = 4 / 16 (blocks x float4 in flight per lane): 2048 x 2 -> 65.5 / 67.0 us,
+    // 1024 x 2 -> 57 / 56, 1024 x 4 -> 62 / 65, 512 x 4 -> 54.4 / 54.1, 512 x 8 -> 59 / 59, 384 x 4 -> 57 / 59,
+    // 256 x 8 -> 70 / 70: about 2048 waves x 4 independent 1 KiB streams is what the HBM controllers like; more
+    // concurrent streams cost more than they hide.  (It also leaves the fold kernel 512 rows instead of 2048.)
+    const int64_t cap = 512;
     if (blocks > cap) blocks = (int)cap;
     if (blocks > max_rows) blocks = (int)max_rows;
     int row_shift = 0;
@@ -1876,8 +1880,8 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
         }
 #define QD_PG_K(IDXB, BK)                                                                                           \
         {                                                                                                           \
-            if (k <= 4) QD_PG(4, IDXB, BK, 2, false)                                                                \
-            else if (!big) QD_PG(0, IDXB, BK, 2, false)                                                             \
+            if (k <= 4) QD_PG(4, IDXB, BK, 4, false)                                                                \
+            else if (!big) QD_PG(0, IDXB, BK, 4, false)                                                             \
             else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
             else QD_PG(0, IDXB, BK, 8, true)                                                                        \
         }

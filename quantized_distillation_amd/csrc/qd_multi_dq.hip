@@ -115,14 +115,31 @@ __global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc*
     int64_t done = 0;
     if (vec) {
         const int64_t n4 = d.n >> 2;
-        for (int64_t i = tid; i < n4; i += nth) {
-            const f4 gv = ldg_nt((const f4*)d.grad + i);
-            const uint32_t pk = ldg_nt((const uint32_t*)d.idx + i);
-            const float a = single ? a_single : ldg(d.alpha + ((i << 2) >> row_shift));
+        auto add4 = [&](const f4& gv, uint32_t pk, float a) {
             col[(pk & 255) * 256] += gv.x * a;           // one fp32 multiply each, quant_functions.py:495
             col[((pk >> 8) & 255) * 256] += gv.y * a;
             col[((pk >> 16) & 255) * 256] += gv.z * a;
             col[(pk >> 24) * 256] += gv.w * a;
+        };
+        constexpr int U = 4;                              // float4 in flight per lane (see qd_point_grad_f32's grid note)
+        int64_t i = tid;
+        for (; i + (U - 1) * nth < n4; i += U * nth) {
+            f4 gv[U]; uint32_t pk[U]; float a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t iu = i + u * nth;
+                gv[u] = ldg_nt((const f4*)d.grad + iu);
+                pk[u] = ldg_nt((const uint32_t*)d.idx + iu);
+                a[u] = single ? a_single : ldg(d.alpha + ((iu << 2) >> row_shift));
+            }
+            __builtin_amdgcn_sched_barrier(0);            // keep the loads together (not sunk to their uses)
+#pragma unroll
+            for (int u = 0; u < U; ++u) add4(gv[u], pk[u], a[u]);
+        }
+        for (; i < n4; i += nth) {
+            const f4 gv = ldg_nt((const f4*)d.grad + i);
+            const uint32_t pk = ldg_nt((const uint32_t*)d.idx + i);
+            add4(gv, pk, single ? a_single : ldg(d.alpha + ((i << 2) >> row_shift)));
         }
         done = n4 << 2;
     }
@@ -167,7 +184,9 @@ int64_t qd_multi_dq_plan(QdDiffQuantDesc* host_table, int ntensors, int64_t buck
         host_table[i].first_tile = tiles;
         host_table[i].first_block = blocks;
         tiles += (nb + 3) / 4;
-        int64_t nblk = (n + 256 * 4 * 8 - 1) / (256 * 4 * 8);          // ~32 elements per thread
+        // ~512 elements per thread: a whole model then runs on a few hundred blocks, each lane streaming four
+        // independent float4 at a time -- the grid shape that measured best for qd_point_grad_f32
+        int64_t nblk = (n + 256 * 4 * 128 - 1) / (256 * 4 * 128);
         if (nblk < 1) nblk = 1;
         if (nblk > 512) nblk = 512;
         blocks += nblk;
