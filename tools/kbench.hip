@@ -77,6 +77,73 @@ __global__ void k_qdq(const float* x, float* q, int64_t nb, float sm1) {
 }
 
 
+// persistent variants: a fixed grid, every wave keeps UT tiles (UT x 4 float4 per lane) in flight per iteration.
+// Question (after the point-gradient grid sweep): do fewer waves with deeper streams also help a read+write kernel?
+template <int UT>
+__global__ __launch_bounds__(256) void k_copy_persist(const f4* x, f4* y, int64_t n4) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t tiles = n4 / 256;                       // 4 float4 per lane per tile
+    for (int64_t t = wave; t < tiles; t += (int64_t)UT * nw) {
+        f4 v[UT][4];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int64_t tt = t + (int64_t)u * nw < tiles ? t + (int64_t)u * nw : tiles - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[u][j] = ld<true>(x + tt * 256 + j * 64 + lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            if (t + (int64_t)u * nw < tiles) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st<true>(v[u][j], y + (t + (int64_t)u * nw) * 256 + j * 64 + lane);
+            }
+        }
+    }
+}
+template <int UT>
+__global__ __launch_bounds__(256) void k_qdq_persist(const float* x, float* q, int64_t nb, float sm1) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, l = lane & 15;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t tiles = nb / 4;
+    for (int64_t t = wave; t < tiles; t += (int64_t)UT * nw) {
+        f4 v[UT][4];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int64_t tt = t + (int64_t)u * nw < tiles ? t + (int64_t)u * nw : tiles - 1;
+            const f4* src = (const f4*)(x + (tt * 4 + sub) * 256 + l * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[u][j] = ld<true>(src + j * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            if (t + (int64_t)u * nw < tiles) {
+                float mn = fminf(fminf(v[u][0].x, v[u][0].y), fminf(v[u][0].z, v[u][0].w));
+                float mx = fmaxf(fmaxf(v[u][0].x, v[u][0].y), fmaxf(v[u][0].z, v[u][0].w));
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    mn = fminf(mn, fminf(fminf(v[u][j].x, v[u][j].y), fminf(v[u][j].z, v[u][j].w)));
+                    mx = fmaxf(mx, fmaxf(fmaxf(v[u][j].x, v[u][j].y), fmaxf(v[u][j].z, v[u][j].w)));
+                }
+                mn = row16_min(mn); mx = row16_max(mx);
+                float a, b; alpha_beta(mn, mx, a, b);
+                f4* dst = (f4*)(q + ((t + (int64_t)u * nw) * 4 + sub) * 256 + l * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f4 r; float lev;
+                    r.x = qdq(v[u][j].x, a, b, sm1, 0.f, lev); r.y = qdq(v[u][j].y, a, b, sm1, 0.f, lev);
+                    r.z = qdq(v[u][j].z, a, b, sm1, 0.f, lev); r.w = qdq(v[u][j].w, a, b, sm1, 0.f, lev);
+                    st<true>(r, dst + j * 16);
+                }
+            }
+        }
+    }
+}
+
 // ---- K6 probes: what bounds the point-gradient stage-1 kernel?  LEVEL 0: read g only (sum);
 // 1: + packed uint8 index loads; 2: + alpha[bucket] loads; 3: + k=4 select-accumulate (the real thing)
 template <int LEVEL, int UNR>
@@ -228,6 +295,28 @@ int main(int argc, char** argv) {
         addb("buf ld sc0(1)  st nt(2)", k_qdq_buf<1, 2>);
         addb("buf ld sc1+nt  st sc1+nt", k_qdq_buf<18, 18>);
         addb("buf ld plain   st plain", k_qdq_buf<0, 0>);
+    } else if (argc > 3 && std::string(argv[3]) == "persist") {
+        auto addcp = [&](const char* nm, auto kern, int blocks) {
+            vs.push_back({nm, [=](int i) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st0, (const f4*)x[i & 3], (f4*)y[i & 3], N / 4); }, {}});
+        };
+        auto addqp = [&](const char* nm, auto kern, int blocks) {
+            vs.push_back({nm, [=](int i) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, st0, (const float*)x[i & 3], y[i & 3], nb, 15.0f); }, {}});
+        };
+        addc("copy nt V4 full", k_copy<true, 4>, 4, 0);
+        addq("qdq nt L16V4 b256 full", k_qdq<true, 16, 4, 0>, 256, nb / 4, 0);
+        addcp("copy persist UT1 2048", k_copy_persist<1>, 2048);
+        addcp("copy persist UT2 1024", k_copy_persist<2>, 1024);
+        addcp("copy persist UT2 2048", k_copy_persist<2>, 2048);
+        addcp("copy persist UT4 512", k_copy_persist<4>, 512);
+        addcp("copy persist UT4 1024", k_copy_persist<4>, 1024);
+        addcp("copy persist UT1 512", k_copy_persist<1>, 512);
+        addqp("qdq persist UT1 2048", k_qdq_persist<1>, 2048);
+        addqp("qdq persist UT2 1024", k_qdq_persist<2>, 1024);
+        addqp("qdq persist UT2 2048", k_qdq_persist<2>, 2048);
+        addqp("qdq persist UT4 512", k_qdq_persist<4>, 512);
+        addqp("qdq persist UT4 1024", k_qdq_persist<4>, 1024);
+        addqp("qdq persist UT1 512", k_qdq_persist<1>, 512);
+        addqp("qdq persist UT2 512", k_qdq_persist<2>, 512);
     } else if (argc > 3 && std::string(argv[3]) == "pg") {
         addp("pg L0 read g only, unr1, 8192 blk", k_pg_probe<0, 1>, 8192);
         addp("pg L0 read g only, unr2, 8192 blk", k_pg_probe<0, 2>, 8192);
