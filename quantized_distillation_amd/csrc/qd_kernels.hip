@@ -352,6 +352,12 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
     const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    // wave-uniform shortcuts of the common configuration (no mean, no clamp, <= 16 levels, deterministic): they
+    // take the kernel from ~43 to ~30 VALU instructions per element, which keeps it HBM-bound on boxes whose
+    // sustained clock is lower (measured: 88 us vs 85.8 us for the leaner kbench kernel on the same box)
+    const bool prep_on = p.mean != nullptr || p.me != INFINITY;
+    const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
+    const float tab = (float)(lane & 15) / p.sm1;
 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -383,8 +389,10 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                     if (prescaled) {
                         a = p.alpha[bkt]; b = p.beta[bkt];
                     } else {
+                        if (prep_on) {
 #pragma unroll
-                        for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
+                            for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
+                        }
                         float mn = fminf(fminf(v[uu][0].x, v[uu][0].y), fminf(v[uu][0].z, v[uu][0].w));
                         float mx = fmaxf(fmaxf(v[uu][0].x, v[uu][0].y), fmaxf(v[uu][0].z, v[uu][0].w));
 #pragma unroll
@@ -409,10 +417,17 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                         if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
                         float side[4];
                         f4 r;
-                        r.x = transform<MODE>(p, T, v[uu][j].x, a, b, pp.mean, rnd[0], side[0]);
-                        r.y = transform<MODE>(p, T, v[uu][j].y, a, b, pp.mean, rnd[1], side[1]);
-                        r.z = transform<MODE>(p, T, v[uu][j].z, a, b, pp.mean, rnd[2], side[2]);
-                        r.w = transform<MODE>(p, T, v[uu][j].w, a, b, pp.mean, rnd[3], side[3]);
+                        if (use_tab) {
+                            r.x = qdq_tab(v[uu][j].x, a, b, p.sm1, pp.mean, side[0], tab);
+                            r.y = qdq_tab(v[uu][j].y, a, b, p.sm1, pp.mean, side[1], tab);
+                            r.z = qdq_tab(v[uu][j].z, a, b, p.sm1, pp.mean, side[2], tab);
+                            r.w = qdq_tab(v[uu][j].w, a, b, p.sm1, pp.mean, side[3], tab);
+                        } else {
+                            r.x = transform<MODE>(p, T, v[uu][j].x, a, b, pp.mean, rnd[0], side[0]);
+                            r.y = transform<MODE>(p, T, v[uu][j].y, a, b, pp.mean, rnd[1], side[1]);
+                            r.z = transform<MODE>(p, T, v[uu][j].z, a, b, pp.mean, rnd[2], side[2]);
+                            r.w = transform<MODE>(p, T, v[uu][j].w, a, b, pp.mean, rnd[3], side[3]);
+                        }
                         __builtin_nontemporal_store(r, dst + j * LPB);
                         store_side4_row<MODE>(p, e, side);
                     }
@@ -434,8 +449,10 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
             if (prescaled) {
                 a = p.alpha[bkt]; b = p.beta[bkt];
             } else {
+                if (prep_on) {
 #pragma unroll
-                for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
+                    for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
+                }
                 float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
                 float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
 #pragma unroll
@@ -460,10 +477,17 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                 if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
                 float side[4];
                 f4 r;
-                r.x = transform<MODE>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0]);
-                r.y = transform<MODE>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1]);
-                r.z = transform<MODE>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2]);
-                r.w = transform<MODE>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3]);
+                if (use_tab) {
+                    r.x = qdq_tab(v[j].x, a, b, p.sm1, pp.mean, side[0], tab);
+                    r.y = qdq_tab(v[j].y, a, b, p.sm1, pp.mean, side[1], tab);
+                    r.z = qdq_tab(v[j].z, a, b, p.sm1, pp.mean, side[2], tab);
+                    r.w = qdq_tab(v[j].w, a, b, p.sm1, pp.mean, side[3], tab);
+                } else {
+                    r.x = transform<MODE>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0]);
+                    r.y = transform<MODE>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1]);
+                    r.z = transform<MODE>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2]);
+                    r.w = transform<MODE>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3]);
+                }
                 __builtin_nontemporal_store(r, dst + j * LPB);
                 store_side4_row<MODE>(p, e, side);
             }
@@ -545,6 +569,9 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
     const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    const bool prep_on = p.mean != nullptr || p.me != INFINITY;
+    const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
+    const float tab = (float)(lane & 15) / p.sm1;
     const int64_t wave = uniform_wave_index();
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 
@@ -567,7 +594,7 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
             for (int j = 0; j < VMAX; ++j) {
                 const int f = lane + 64 * j;
                 if (j < nj && f < nf) {
-                    v[j] = prep4(v[j], pp);
+                    if (prep_on) v[j] = prep4(v[j], pp);
                     float mn = fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w));
                     const float mx = fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w));
                     if (has_nan4(v[j])) mn = NAN;      // carried as a NaN minimum (v_min would drop it)
@@ -610,19 +637,28 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
 #pragma unroll
         for (int j = 0; j < VMAX; ++j) {
             const int f = lane + 64 * j;
-            if (j < nj && f < nf) {
-                const float2 s = ab[q];
+            if (j < nj) {                                  // whole wave: lanes past the chunk work on their duplicate
+                const float2 s = ab[q < m ? q : m - 1];
                 const int64_t e = e0 + ((int64_t)f << 2);
-                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
                 float side[4];
                 f4 o;
-                o.x = transform<MODE>(p, T, v[j].x, s.x, s.y, pp.mean, rnd[0], side[0]);
-                o.y = transform<MODE>(p, T, v[j].y, s.x, s.y, pp.mean, rnd[1], side[1]);
-                o.z = transform<MODE>(p, T, v[j].z, s.x, s.y, pp.mean, rnd[2], side[2]);
-                o.w = transform<MODE>(p, T, v[j].w, s.x, s.y, pp.mean, rnd[3], side[3]);
-                __builtin_nontemporal_store(o, dst + f);
-                store_side4<MODE>(p, e, side);
+                if (use_tab) {                             // <= 16 levels, deterministic: see k_bucket_vec
+                    o.x = qdq_tab(v[j].x, s.x, s.y, p.sm1, pp.mean, side[0], tab);
+                    o.y = qdq_tab(v[j].y, s.x, s.y, p.sm1, pp.mean, side[1], tab);
+                    o.z = qdq_tab(v[j].z, s.x, s.y, p.sm1, pp.mean, side[2], tab);
+                    o.w = qdq_tab(v[j].w, s.x, s.y, p.sm1, pp.mean, side[3], tab);
+                } else {
+                    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                    o.x = transform<MODE>(p, T, v[j].x, s.x, s.y, pp.mean, rnd[0], side[0]);
+                    o.y = transform<MODE>(p, T, v[j].y, s.x, s.y, pp.mean, rnd[1], side[1]);
+                    o.z = transform<MODE>(p, T, v[j].z, s.x, s.y, pp.mean, rnd[2], side[2]);
+                    o.w = transform<MODE>(p, T, v[j].w, s.x, s.y, pp.mean, rnd[3], side[3]);
+                }
+                if (f < nf) {
+                    __builtin_nontemporal_store(o, dst + f);
+                    store_side4<MODE>(p, e, side);
+                }
             }
             q += step_q; r += step_r;
             if (r >= Bq) { r -= Bq; ++q; }
@@ -669,6 +705,9 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
     const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    const bool prep_on = p.mean != nullptr || p.me != INFINITY;
+    const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
+    const float tab = (float)(lane & 15) / p.sm1;
     const int64_t wave = uniform_wave_index();
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 
@@ -688,7 +727,7 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
             for (int j = 0; j < VMAX; ++j) {
                 const int f = lane + 64 * j;
                 if (j < nj && f < nf) {
-                    v[j] = prep4(v[j], pp);
+                    if (prep_on) v[j] = prep4(v[j], pp);
                     ((f4*)vals)[f] = v[j];
                 }
             }
@@ -727,21 +766,34 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
 #pragma unroll
         for (int j = 0; j < VMAX; ++j) {
             const int f = lane + 64 * j;
-            if (j < nj && f < nf) {
-                const float2 s0 = ab[q];
-                const float2 s1 = ab[q + 1 < m ? q + 1 : q];
+            if (j < nj) {                                  // whole wave: lanes past the chunk work on their duplicate
+                const int qa = q < m ? q : m - 1, qb = q + 1 < m ? q + 1 : m - 1;
+                const float2 s0 = ab[qa];
+                const float2 s1 = ab[qb];
                 const int cut = B - r;                  // elements c >= cut of this float4 belong to bucket q + 1
                 const int64_t e = e0 + ((int64_t)f << 2);
-                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                const float a1 = 1 >= cut ? s1.x : s0.x, b1 = 1 >= cut ? s1.y : s0.y;
+                const float a2 = 2 >= cut ? s1.x : s0.x, b2 = 2 >= cut ? s1.y : s0.y;
+                const float a3 = 3 >= cut ? s1.x : s0.x, b3 = 3 >= cut ? s1.y : s0.y;
                 float side[4];
                 f4 o;
-                o.x = transform<MODE>(p, T, v[j].x, s0.x, s0.y, pp.mean, rnd[0], side[0]);
-                o.y = transform<MODE>(p, T, v[j].y, 1 >= cut ? s1.x : s0.x, 1 >= cut ? s1.y : s0.y, pp.mean, rnd[1], side[1]);
-                o.z = transform<MODE>(p, T, v[j].z, 2 >= cut ? s1.x : s0.x, 2 >= cut ? s1.y : s0.y, pp.mean, rnd[2], side[2]);
-                o.w = transform<MODE>(p, T, v[j].w, 3 >= cut ? s1.x : s0.x, 3 >= cut ? s1.y : s0.y, pp.mean, rnd[3], side[3]);
-                __builtin_nontemporal_store(o, dst + f);
-                store_side4<MODE>(p, e, side);
+                if (use_tab) {
+                    o.x = qdq_tab(v[j].x, s0.x, s0.y, p.sm1, pp.mean, side[0], tab);
+                    o.y = qdq_tab(v[j].y, a1, b1, p.sm1, pp.mean, side[1], tab);
+                    o.z = qdq_tab(v[j].z, a2, b2, p.sm1, pp.mean, side[2], tab);
+                    o.w = qdq_tab(v[j].w, a3, b3, p.sm1, pp.mean, side[3], tab);
+                } else {
+                    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                    o.x = transform<MODE>(p, T, v[j].x, s0.x, s0.y, pp.mean, rnd[0], side[0]);
+                    o.y = transform<MODE>(p, T, v[j].y, a1, b1, pp.mean, rnd[1], side[1]);
+                    o.z = transform<MODE>(p, T, v[j].z, a2, b2, pp.mean, rnd[2], side[2]);
+                    o.w = transform<MODE>(p, T, v[j].w, a3, b3, pp.mean, rnd[3], side[3]);
+                }
+                if (f < nf) {
+                    __builtin_nontemporal_store(o, dst + f);
+                    store_side4<MODE>(p, e, side);
+                }
             }
             q += step_q; r += step_r;
             if (r >= B) { r -= B; ++q; }
@@ -1479,6 +1531,8 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* __res
     Prep pp;
     pp.mean = 0.0f;
     pp.me = INFINITY;
+    const bool use_tab = sm1 <= 15.0f;
+    const float tab = (float)(lane & 15) / sm1;
     for (int64_t t = wave; t < total_tiles; t += nwaves) {
         int lo_t = 0, hi_t = ntensors - 1;               // last tensor with first_tile <= t
         while (lo_t < hi_t) {
@@ -1523,10 +1577,17 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* __res
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 f4 r;
-                r.x = qdq(v[j].x, a, b, sm1, 0.0f, lev);
-                r.y = qdq(v[j].y, a, b, sm1, 0.0f, lev);
-                r.z = qdq(v[j].z, a, b, sm1, 0.0f, lev);
-                r.w = qdq(v[j].w, a, b, sm1, 0.0f, lev);
+                if (use_tab) {                             // <= 16 levels: see k_bucket_vec (a DPP row is active as a whole here)
+                    r.x = qdq_tab(v[j].x, a, b, sm1, 0.0f, lev, tab);
+                    r.y = qdq_tab(v[j].y, a, b, sm1, 0.0f, lev, tab);
+                    r.z = qdq_tab(v[j].z, a, b, sm1, 0.0f, lev, tab);
+                    r.w = qdq_tab(v[j].w, a, b, sm1, 0.0f, lev, tab);
+                } else {
+                    r.x = qdq(v[j].x, a, b, sm1, 0.0f, lev);
+                    r.y = qdq(v[j].y, a, b, sm1, 0.0f, lev);
+                    r.z = qdq(v[j].z, a, b, sm1, 0.0f, lev);
+                    r.w = qdq(v[j].w, a, b, sm1, 0.0f, lev);
+                }
                 stg_nt(r, dst + j * 16);
             }
         } else {
