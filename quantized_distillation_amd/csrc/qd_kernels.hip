@@ -355,9 +355,11 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     // wave-uniform shortcuts of the common configuration (no mean, no clamp, <= 16 levels, deterministic): they
     // take the kernel from ~43 to ~30 VALU instructions per element, which keeps it HBM-bound on boxes whose
     // sustained clock is lower (measured: 88 us vs 85.8 us for the leaner kbench kernel on the same box)
-    const bool prep_on = p.mean != nullptr || p.me != INFINITY;
+    // (MODE_QDQ only, so that the code generated for the other modes is untouched: the point-search kernels are
+    // sensitive to it -- K5 at k = 256 went from 112 to 124 us when these branches were compiled into them.)
+    const bool prep_on = MODE != MODE_QDQ || p.mean != nullptr || p.me != INFINITY;
     const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
-    const float tab = (float)(lane & 15) / p.sm1;
+    const float tab = MODE == MODE_QDQ ? (float)(lane & 15) / p.sm1 : 0.0f;
 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                     if (prescaled) {
                         a = p.alpha[bkt]; b = p.beta[bkt];
                     } else {
-                        if (prep_on) {
+                        if (MODE != MODE_QDQ || prep_on) {
 #pragma unroll
                             for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
                         }
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                         if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
                         float side[4];
                         f4 r;
-                        if (use_tab) {
+                        if (MODE == MODE_QDQ && use_tab) {
                             r.x = qdq_tab(v[uu][j].x, a, b, p.sm1, pp.mean, side[0], tab);
                             r.y = qdq_tab(v[uu][j].y, a, b, p.sm1, pp.mean, side[1], tab);
                             r.z = qdq_tab(v[uu][j].z, a, b, p.sm1, pp.mean, side[2], tab);
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
             if (prescaled) {
                 a = p.alpha[bkt]; b = p.beta[bkt];
             } else {
-                if (prep_on) {
+                if (MODE != MODE_QDQ || prep_on) {
 #pragma unroll
                     for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
                 }
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                 if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
                 float side[4];
                 f4 r;
-                if (use_tab) {
+                if (MODE == MODE_QDQ && use_tab) {
                     r.x = qdq_tab(v[j].x, a, b, p.sm1, pp.mean, side[0], tab);
                     r.y = qdq_tab(v[j].y, a, b, p.sm1, pp.mean, side[1], tab);
                     r.z = qdq_tab(v[j].z, a, b, p.sm1, pp.mean, side[2], tab);
