@@ -264,6 +264,25 @@ __device__ __forceinline__ float qdq_stochastic(float v, float a, float b, float
     return y;
 }
 
+// stochastic variant with the same per-row table for floor(t) / sm1 (levels <= 16)
+__device__ __forceinline__ float qdq_stochastic_tab(float v, float a, float b, float sm1, float mean, float rnd,
+                                                    float& level, float tab) {
+    float u = v - b;
+    u = u / a;
+    float t = u * sm1;
+    float l = floorf(t);
+    float p = t - l;
+    const int src = (int)(threadIdx.x & 48) + (int)l;
+    float w = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(tab)));
+    float inc = (rnd <= p) ? (1.0f / sm1) : 0.0f;
+    level = l + ((rnd <= p) ? 1.0f : 0.0f);
+    w = w + inc;
+    float y = w * a;
+    y = y + b;
+    y = y + mean;
+    return y;
+}
+
 // ---- sorted-array searches over LDS (uniform trip count, branch-free) ----
 // count of a[j] <  u (lower bound) when UPPER == false; count of a[j] <= u when UPPER == true
 template <bool UPPER>

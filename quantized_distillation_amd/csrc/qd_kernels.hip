@@ -359,6 +359,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     // sensitive to it -- K5 at k = 256 went from 112 to 124 us when these branches were compiled into them.)
     const bool prep_on = MODE != MODE_QDQ || p.mean != nullptr || p.me != INFINITY;
     const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
+    const bool use_tab_s = MODE == MODE_QDQ && p.stochastic && p.sm1 <= 15.0f;
     const float tab = MODE == MODE_QDQ ? (float)(lane & 15) / p.sm1 : 0.0f;
 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -424,6 +425,11 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                             r.y = qdq_tab(v[uu][j].y, a, b, p.sm1, pp.mean, side[1], tab);
                             r.z = qdq_tab(v[uu][j].z, a, b, p.sm1, pp.mean, side[2], tab);
                             r.w = qdq_tab(v[uu][j].w, a, b, p.sm1, pp.mean, side[3], tab);
+                        } else if (MODE == MODE_QDQ && use_tab_s) {
+                            r.x = qdq_stochastic_tab(v[uu][j].x, a, b, p.sm1, pp.mean, rnd[0], side[0], tab);
+                            r.y = qdq_stochastic_tab(v[uu][j].y, a, b, p.sm1, pp.mean, rnd[1], side[1], tab);
+                            r.z = qdq_stochastic_tab(v[uu][j].z, a, b, p.sm1, pp.mean, rnd[2], side[2], tab);
+                            r.w = qdq_stochastic_tab(v[uu][j].w, a, b, p.sm1, pp.mean, rnd[3], side[3], tab);
                         } else {
                             r.x = transform<MODE>(p, T, v[uu][j].x, a, b, pp.mean, rnd[0], side[0]);
                             r.y = transform<MODE>(p, T, v[uu][j].y, a, b, pp.mean, rnd[1], side[1]);
@@ -484,6 +490,11 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
                     r.y = qdq_tab(v[j].y, a, b, p.sm1, pp.mean, side[1], tab);
                     r.z = qdq_tab(v[j].z, a, b, p.sm1, pp.mean, side[2], tab);
                     r.w = qdq_tab(v[j].w, a, b, p.sm1, pp.mean, side[3], tab);
+                } else if (MODE == MODE_QDQ && use_tab_s) {
+                    r.x = qdq_stochastic_tab(v[j].x, a, b, p.sm1, pp.mean, rnd[0], side[0], tab);
+                    r.y = qdq_stochastic_tab(v[j].y, a, b, p.sm1, pp.mean, rnd[1], side[1], tab);
+                    r.z = qdq_stochastic_tab(v[j].z, a, b, p.sm1, pp.mean, rnd[2], side[2], tab);
+                    r.w = qdq_stochastic_tab(v[j].w, a, b, p.sm1, pp.mean, rnd[3], side[3], tab);
                 } else {
                     r.x = transform<MODE>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0]);
                     r.y = transform<MODE>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1]);
@@ -1691,6 +1702,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             case 1024: QD_VEC(64, 4, 1)
             case 2048: QD_VEC(64, 8, 1)
             case 4096: QD_VEC(64, 16, 1)
+            case 8192: QD_VEC(64, 32, 1)
             default: break;
         }
     }
