@@ -32,6 +32,10 @@ def record(label, kernel, algo_bytes, fn):
 keep = []
 record('K1 uniform 4-bit bucket 256', 'k_bucket_vec<0, 16, 4, 1>', 8 * N,
        lambda i: keep.append(quantization.uniformQuantization(xs[i], 16, bucket_size=256)[0]))
+record('K1 uniform 4-bit bucket 100 (chunk kernel)', 'k_bucket_chunk<0, 8>', 8 * N,
+       lambda i: keep.append(quantization.uniformQuantization(xs[i + 3], 16, bucket_size=100)[0]))
+record('K1 uniform 4-bit bucket 33 (chunk_any kernel)', 'k_bucket_chunk_any<0, 8>', 8 * N,
+       lambda i: keep.append(quantization.uniformQuantization(xs[i], 16, bucket_size=33)[0]))
 sf = quantization.ScalingFunction('linear', False, False, 256)
 record('K2 scale_down', 'k_bucket_vec<1, 16, 4, 1>', 8 * N, lambda i: keep.append(sf.scale_down(xs[i + 3])))
 u = sf.scale_down(xs[0])
@@ -43,7 +47,7 @@ fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process
 # (preprocess ran K2 three more times)
 counts['k_bucket_vec<1, 16, 4, 1>'] = counts.get('k_bucket_vec<1, 16, 4, 1>', 0) + 4   # + sf.scale_down(xs[0]) above
 record('K5 diff-quant forward k=4 u8 idx', 'k_bucket_vec<2, 16, 4, 1>', 9 * N, lambda i: keep.append(fns[i].forward(None, pts)))
-record('K6 point gradient k=4 u8 idx', 'k_point_grad_fast<4, 1, true>', 5 * N, lambda i: keep.append(fns[i].backward(gs[i])[1]))
+record('K6 point gradient k=4 u8 idx', 'k_point_grad_fast<4, 1, true', 5 * N, lambda i: keep.append(fns[i].backward(gs[i])[1]))
 fq = quantization.uniformQuantization_variable(16, bucket_size=256)
 
 
@@ -58,7 +62,8 @@ pk = codec.pack_uniform(xs[0], 16, 256)
 counts['k_pack_vec<16, 4, 4>'] += 1
 record('UPK unpack 4-bit', 'k_unpack<4>', int(4.5 * N), lambda i: keep.append(pk.unpack()))
 torch.cuda.synchronize()
-os.makedirs('gpurun_out', exist_ok=True)
-with open('gpurun_out/pmc_plan.json', 'w') as f:
+out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+os.makedirs(out_dir, exist_ok=True)
+with open(os.path.join(out_dir, 'pmc_plan.json'), 'w') as f:
     json.dump(plan, f, indent=1)
 print('ok', len(plan))
