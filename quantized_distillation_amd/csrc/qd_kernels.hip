@@ -1736,6 +1736,15 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             return check_launch();
         }
     }
+    if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row > 512 && p.row <= 1024) {     // four buckets per chunk, 16 float4 per lane
+        const int64_t nchunks = nfull / 4;
+        if (nchunks > 0) {
+            const size_t lds = (size_t)2 * (16 * 128 + 256) * sizeof(float2);
+            const int blocks = blocks_for(nchunks, 2) + 1;
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds, st, p, 4, nchunks);
+            return check_launch();
+        }
+    }
     if (p.row <= 256) {                                  // 16 buckets per block, a DPP row each
         hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16)), dim3(256), 0, st, p);
     } else if (p.row <= 16384) {                         // 4 buckets per block, one wave each
