@@ -85,3 +85,62 @@ def test_c_random_vs_numpy():
         assert np.array_equal(a['q'], b['q']) and np.array_equal(a['lev'].reshape(-1)[:n], b['lev'])
         assert np.array_equal(a['imin'].reshape(-1), b['imin']) and np.array_equal(a['imax'].reshape(-1), b['imax'])
     assert oc.max_threads() >= 1
+
+
+# ---- property-based: the C oracle (the checker of the GPU property tests) against the numpy oracle (pinned to
+# the reference's golden vectors line by line) on random sizes / buckets / levels / distributions, CPU only
+from hypothesis import HealthCheck, given, settings          # noqa: E402
+from hypothesis import strategies as st                       # noqa: E402
+
+_buckets = st.sampled_from([None, 256, 64, 100, 7, 1, 33, 1000, 4, 2048, 513])
+_sizes = st.one_of(st.integers(1, 600), st.integers(600, 20000))
+
+
+def _make(n, seed, kind):
+    rng = np.random.RandomState(seed)
+    x = [rng.randn(n), rng.randn(n) * 1e-3 + 5.0, rng.randint(-4, 5, size=n).astype(np.float64), np.full(n, 0.25),
+         rng.standard_cauchy(n), rng.rand(n) * 1e-30][kind]
+    return x.astype(np.float32)
+
+
+@settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(n=_sizes, bucket=_buckets, s=st.sampled_from([2, 3, 4, 16, 255, 256, 1000]), seed=st.integers(0, 2 ** 31 - 1),
+       kind=st.integers(0, 5), clamp=st.sampled_from([False, 0.5, 2.0]), sub=st.booleans())
+def test_c_uniform_property_vs_numpy(n, bucket, s, seed, kind, clamp, sub):
+    x = _make(n, seed, kind)
+    mean = float(np.float32(x.astype(np.float64).mean())) if sub else None
+    a = onp.uniform_quantize(x, s, bucket, clamp, sub, mean=mean)
+    b = oc.uniform_quantize(x, s, bucket, clamp, sub, mean=mean)
+    assert np.array_equal(a['q'], b['q'])
+    assert np.array_equal(a['alpha'].reshape(-1), b['alpha']) and np.array_equal(a['beta'].reshape(-1), b['beta'])
+    assert np.array_equal(a['imin'].reshape(-1), b['imin']) and np.array_equal(a['imax'].reshape(-1), b['imax'])
+    assert np.array_equal(a['lev'].reshape(-1)[:n], b['lev'])
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(n=_sizes, bucket=_buckets, k=st.sampled_from([1, 2, 3, 4, 16, 17, 64, 200]), seed=st.integers(0, 2 ** 31 - 1),
+       kind=st.integers(0, 3), dup=st.booleans())
+def test_c_nonuniform_property_vs_numpy(n, bucket, k, seed, kind, dup):
+    x = _make(n, seed, kind)
+    rng = np.random.RandomState(seed ^ 0x5bd1)
+    pts = np.sort(rng.rand(k)).astype(np.float32)
+    if dup and k > 2:
+        pts[1], pts[-1] = pts[0], pts[-2]
+    for mode in ('distance', 'midpoint'):
+        a = onp.nonuniform_quantize(x, pts, bucket, mode)
+        b = oc.nonuniform_quantize(x, pts, bucket, mode)
+        assert np.array_equal(np.asarray(a['idx']).reshape(-1)[:n], b['idx'].reshape(-1)), mode
+        assert np.array_equal(a['q'], b['q']), mode
+    g = rng.randn(n).astype(np.float32)
+    got, absum = oc.point_grad(g, b['idx'], b['alpha'], bucket, k)
+    want, _ = onp.point_grad(g, b['idx'], b['alpha'], bucket, k)
+    assert np.all(np.abs(got - np.asarray(want, dtype=np.float64).reshape(-1)) <= 4e-6 * absum + 1e-30)
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+@given(n=_sizes, bucket=st.sampled_from([64, 256, 100, 7, 1024]), s=st.sampled_from([2, 4, 16, 256]),
+       seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 3))
+def test_c_ste_property_vs_numpy(n, bucket, s, seed, kind):
+    x = _make(n, seed, kind)
+    g = np.random.RandomState(seed ^ 77).randn(n).astype(np.float32)
+    assert np.array_equal(oc.ste_complicated_backward(x, g, s, bucket), onp.ste_complicated_backward(x, g, s, bucket))
