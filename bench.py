@@ -425,23 +425,38 @@ def main():
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         q, sf = quantization.uniformQuantization(xs[0], LEVELS, bucket_size=BUCKET)
-        cpu = cpu_baseline(x_host, q.cpu().numpy(), sf.alpha.cpu().numpy().reshape(-1))
-        parity = cpu.pop('gpu_result_bit_exact')
+        try:
+            cpu = cpu_baseline(x_host, q.cpu().numpy(), sf.alpha.cpu().numpy().reshape(-1))
+            parity = cpu.pop('gpu_result_bit_exact')
+        except Exception as e:                                    # noqa: BLE001  (keep the headline; say what failed)
+            import traceback
+            sys.stderr.write(traceback.format_exc())
+            cpu = {'error': '%s: %s' % (type(e).__name__, e)}
         del q, sf
+
+    # The steps/sec legs are reported alongside the headline; a failure in one of them (say, an out-of-memory
+    # condition on a shared box) is recorded in the JSON instead of losing the headline measurement above.
+    def leg(fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except Exception as e:                                    # noqa: BLE001
+            import traceback
+            sys.stderr.write(traceback.format_exc())
+            return {'error': '%s: %s' % (type(e).__name__, e)}
 
     distill = None
     if not args.no_distill:
         del live[:], xs[1:]
         torch.cuda.empty_cache()
-        distill = distill_steps_per_sec(dev, rank, n_gpus, distributed)
+        distill = leg(distill_steps_per_sec, dev, rank, n_gpus, distributed)
         if n_gpus == 1 and not args.no_diffquant:
             torch.cuda.empty_cache()
-            distill['diffquant_wrn'] = diffquant_steps_per_sec(dev)
+            distill['diffquant_wrn'] = leg(diffquant_steps_per_sec, dev)
         # configs[3] is quoted on 8 GPUs, configs[4] on 4: run them where BASELINE.json places them
         if n_gpus == 8 or os.environ.get('QD_BENCH_CFG4') == '1':
-            distill['imagenet_resnet18k_dp'] = dp_config_steps_per_sec('imagenet', dev, rank, n_gpus, distributed)
+            distill['imagenet_resnet18k_dp'] = leg(dp_config_steps_per_sec, 'imagenet', dev, rank, n_gpus, distributed)
         if n_gpus == 4 or os.environ.get('QD_BENCH_CFG5') == '1':
-            distill['nmt_lstm_dp'] = dp_config_steps_per_sec('nmt', dev, rank, n_gpus, distributed)
+            distill['nmt_lstm_dp'] = leg(dp_config_steps_per_sec, 'nmt', dev, rank, n_gpus, distributed)
 
     # RCCL writes a version banner to the C-level stdout, which is block-buffered when piped and would
     # otherwise be flushed at exit, i.e. after the JSON line: push it out now on every rank, so that the JSON
