@@ -13,13 +13,18 @@ through HBM and cannot be served from the 256 MiB Infinity Cache.
 
 Multi-GPU (one process per GPU): the path shards by tensor -- every rank quantizes its own
 tensors, no collective in the data path -- so scaling is "weak" and value = total bytes of all
-ranks / max-over-ranks time.
+ranks / max-over-ranks time.  `python bench.py --gpus N` started WITHOUT a torchrun environment
+launches the N ranks itself (harness/launch.py re-executes this file under
+torch.distributed.run, 127.0.0.1 rendezvous, backend "nccl" = RCCL); started under torchrun it
+uses the ranks it was given.  At N=1 a single-rank RCCL group is still created, so the gradient
+all-reduce of the steps/sec legs really runs through RCCL on a one-GPU box.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      achieved algorithmic GB/s of the dominant kernel (8 B/element: 4 read + 4 written,
                 SURVEY.md 8d) from HIP-event timing of the timed region, against the 8 TB/s peak
-  cpu_baseline  the same algorithm on the host cores (C port of the reference, OpenMP) on a
-                bounded sample, and the op-for-op torch CPU port of the reference next to it.
+  cpu_baseline  the REFERENCE's own uniformQuantization (staged bytecode of
+                /root/reference/quantization, oracle/ref_stage.py) timed on the host cores of this
+                box on the same workload, with the two ports (C/OpenMP, torch ops) next to it.
 """
 import argparse
 import json
@@ -52,61 +57,99 @@ def cpu_model():
     return 'unknown'
 
 
+def _time_runs(fn, min_runs, budget_s):
+    """Warm-up + >= min_runs timed runs (more while the time budget lasts, at most 10)."""
+    fn()
+    ts = []
+    t_end = time.time() + budget_s
+    while len(ts) < min_runs or (len(ts) < 10 and time.time() < t_end):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
 def cpu_baseline(x_host, q_gpu, alpha_gpu):
-    """The reference's algorithm on the host cores, same workload, bounded sample; the oracle's
-    output doubles as the checker of the GPU result for the same tensor (q_gpu, alpha_gpu)."""
+    """The reference's own quantizer on the host cores of this box, same workload (bounded sample);
+    its output doubles as the checker of the GPU result for the same tensor (q_gpu, alpha_gpu).
+    ref: quantization/quant_functions.py:155-194."""
     import numpy as np
-    from oracle import oracle_c
+    from oracle import oracle_c, ref_stage
     from oracle.torch_port import uniform_quantize_torch_ops
-    oracle_c.build()
-    cores = oracle_c.max_threads()
     xn = x_host.numpy()
     n = xn.size
+    ncpu = os.cpu_count() or 1
+    out = {'unit': 'GB/s', 'cpu_model': cpu_model(), 'os_cpu_count': ncpu}
+
+    refq = ref_stage.load()
+    if refq is not None:
+        # torch's elementwise CPU ops oversubscribe badly with one thread per SMT sibling on a 2-socket box
+        # (0.3 GB/s at 256 threads in round 1), so the reference is timed at several thread counts and the BEST is
+        # the baseline; os.cpu_count() threads -- what the survey prescribes -- is always among them.
+        counts = sorted({ncpu, max(1, ncpu // 2), min(ncpu, 64), min(ncpu, 32)}, reverse=True)
+        per_threads, best = {}, None
+        for th in counts:
+            torch.set_num_threads(th)
+            ts = _time_runs(lambda: refq.uniformQuantization(x_host, LEVELS, bucket_size=BUCKET), 5, 4.0)
+            per_threads[str(th)] = {'min_s': round(min(ts), 4), 'median_s': round(float(np.median(ts)), 4), 'runs': len(ts),
+                                    'GBps_at_min': round(ALGO_BYTES_PER_ELEM * n / min(ts) / 1e9, 3)}
+            if best is None or min(ts) < best[1]:
+                best = (th, min(ts), float(np.median(ts)), len(ts))
+        torch.set_num_threads(best[0])
+        q_ref, sf_ref = refq.uniformQuantization(x_host, LEVELS, bucket_size=BUCKET)
+        out.update({
+            'value': round(ALGO_BYTES_PER_ELEM * n / best[1] / 1e9, 3), 'cores': best[0], 'kind': 'reference',
+            'sample': "%d runs after 1 warm-up of the full workload (N=%d fp32, s=%d, bucket=%d) with the reference's own "
+                      'quantization.uniformQuantization (bytecode of /root/reference/quantization staged by oracle/ref_stage.py), '
+                      'torch %s CPU ops, torch.set_num_threads(%d) = best of the thread counts tried; min %.4f s, median %.4f s'
+                      % (best[3], n, LEVELS, BUCKET, torch.__version__, best[0], best[1], best[2]),
+            'threads_tried': per_threads,
+            'reference_sources_sha256': (ref_stage.manifest() or {}).get('files'),
+        })
+        bit_exact = bool(np.array_equal(q_gpu, q_ref.numpy()) and
+                         np.array_equal(alpha_gpu, sf_ref.alpha.numpy().reshape(-1)))
+        out['gpu_result_bit_exact_vs_reference'] = bit_exact
+        del q_ref, sf_ref
+    else:
+        out['reference_error'] = ('oracle/_ref is not staged (run __graft_entry__.build() where /root/reference exists); '
+                                  'falling back to the C port as the baseline')
+
+    # secondary: the two ports of the same algorithm (test infrastructure, oracle/)
+    oracle_c.build()
+    cores = oracle_c.max_threads()
     ref = oracle_c.uniform_quantize(xn, LEVELS, BUCKET, want_idx=False, want_lev=False)       # warm-up + checker
-    bit_exact = bool(np.array_equal(q_gpu, ref['q']) and np.array_equal(alpha_gpu, ref['alpha']))
+    out['gpu_result_bit_exact'] = bool(np.array_equal(q_gpu, ref['q']) and np.array_equal(alpha_gpu, ref['alpha']))
     del ref
-    times = []
-    t_end = time.time() + 12.0
-    while len(times) < 10 and (time.time() < t_end or len(times) < 3):
-        t0 = time.perf_counter()
-        oracle_c.uniform_quantize(xn, LEVELS, BUCKET, want_idx=False, want_lev=False)
-        times.append(time.perf_counter() - t0)
-    best, med = min(times), float(np.median(times))
-    out = {
-        'value': round(ALGO_BYTES_PER_ELEM * n / best / 1e9, 3), 'unit': 'GB/s', 'cores': cores, 'kind': 'port',
-        'sample': '%d runs of the full workload (N=%d fp32, s=%d, bucket=%d); C port of the reference '
-                  'algorithm (oracle/qd_oracle.c, OpenMP over buckets); min %.4f s, median %.4f s'
-                  % (len(times), n, LEVELS, BUCKET, best, med),
-        'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(), 'gpu_result_bit_exact': bit_exact,
-        'port_vs_reference': 'on identical cores (authoring container, profiles/r01_reference_cpu_timing.json) the '
-                             'reference itself runs this workload at 5.2 GB/s, torch_ops_port at 4.9 (0.95 x), this C '
-                             'port at 8.5 (1.64 x); both ports are bit-identical to the reference output',
-    }
-    # the reference's own op chain (multi-threaded torch CPU ops), restated in oracle/torch_port.py
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))     # 256 SMT threads oversubscribe torch's elementwise ops
-    uniform_quantize_torch_ops(x_host, LEVELS, BUCKET)
-    tt = []
-    t_end = time.time() + 12.0
-    while len(tt) < 5 and (time.time() < t_end or len(tt) < 2):
-        t0 = time.perf_counter()
-        uniform_quantize_torch_ops(x_host, LEVELS, BUCKET)
-        tt.append(time.perf_counter() - t0)
+    ts = _time_runs(lambda: oracle_c.uniform_quantize(xn, LEVELS, BUCKET, want_idx=False, want_lev=False), 3, 6.0)
+    out['c_port'] = {'value': round(ALGO_BYTES_PER_ELEM * n / min(ts) / 1e9, 3), 'unit': 'GB/s', 'threads': cores,
+                     'sample': '%d runs, min %.4f s, median %.4f s; oracle/qd_oracle.c, OpenMP over buckets'
+                               % (len(ts), min(ts), float(np.median(ts)))}
+    if 'value' not in out:
+        out.update({'value': out['c_port']['value'], 'cores': cores, 'kind': 'port', 'sample': out['c_port']['sample']})
+    torch.set_num_threads(min(ncpu, 64))
+    tt = _time_runs(lambda: uniform_quantize_torch_ops(x_host, LEVELS, BUCKET), 3, 6.0)
     out['torch_ops_port'] = {
-        'value': round(ALGO_BYTES_PER_ELEM * n / min(tt) / 1e9, 3), 'unit': 'GB/s',
-        'threads': torch.get_num_threads(),
+        'value': round(ALGO_BYTES_PER_ELEM * n / min(tt) / 1e9, 3), 'unit': 'GB/s', 'threads': torch.get_num_threads(),
         'sample': '%d runs, min %.4f s, median %.4f s; same sequence of torch CPU ops as '
-                  'quantization/quant_functions.py:155-194' % (len(tt), min(tt), float(np.median(tt))),
+                  'quantization/quant_functions.py:155-194 (oracle/torch_port.py)' % (len(tt), min(tt), float(np.median(tt))),
     }
-    out['distill'] = cpu_distill_baseline()
+    out['distill'] = cpu_distill_baseline(refq)
     return out
 
 
-def cpu_distill_baseline(steps=12, warmup=2, batch=50):
+def cpu_distill_baseline(refq=None, steps=12, warmup=2, batch=50):
     """BASELINE configs[0]: the CIFAR10 ConvolForwardNet student step on the CPU with the
-    reference's quantizer (its torch-op chain, oracle/torch_port.py) in the reference's loop shape
-    (quantize every parameter, fwd/bwd with the KD loss, restore, SGD) -- bounded sample."""
+    reference's own quantizer (staged bytecode; its torch-op port when nothing is staged) in the
+    reference's loop shape (quantize every parameter, fwd/bwd with the KD loss, restore, SGD) --
+    bounded sample."""
     from harness import models
     from oracle.torch_port import uniform_quantize_torch_ops
+    if refq is not None:
+        def quantize_one(t):
+            return refq.uniformQuantization(t, 16, bucket_size=256)[0]
+    else:
+        def quantize_one(t):
+            return uniform_quantize_torch_ops(t, 16, 256)[0]
     torch.manual_seed(0)
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
@@ -121,7 +164,7 @@ def cpu_distill_baseline(steps=12, warmup=2, batch=50):
         a = time.perf_counter()
         saved = [p.data for p in st.parameters()]
         for p in st.parameters():
-            p.data = uniform_quantize_torch_ops(p.data, 16, 256)[0]
+            p.data = quantize_one(p.data)
         t_quant += time.perf_counter() - a
         opt.zero_grad()
         with torch.no_grad():
@@ -140,8 +183,9 @@ def cpu_distill_baseline(steps=12, warmup=2, batch=50):
     dt = time.perf_counter() - t0
     return {'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2),
             'quantize_ms_per_step': round(t_quant / steps * 1e3, 3), 'threads': threads,
+            'quantizer': 'reference (oracle/_ref bytecode)' if refq is not None else 'torch-op port (oracle/torch_port.py)',
             'sample': '%d steps, batch %d, synthetic CIFAR10-shaped data; student+teacher fwd, KD loss, bwd, SGD on the '
-                      'host with the torch-op port of the reference quantizer (configs[0])' % (steps, batch)}
+                      'host with the reference quantizer in the loop (configs[0])' % (steps, batch)}
 
 
 def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, per_gpu_batch=50):
@@ -233,7 +277,8 @@ def dp_config_steps_per_sec(kind, dev, rank, n_gpus, distributed, steps=10, warm
         per_gpu = 64
         tr = DistillTrainer(models.Seq2SeqLSTM(), models.Seq2SeqLSTM(), dev, num_bits=4, bucket_size=256, lr=1.0,
                             momentum=0.0, nesterov=False, weight_decay=0.0, loss_fn=seq2seq_kd_loss_fn, clip_norm=5.0,
-                            grad_chunks=4, overlap_allreduce=True)
+                            grad_chunks=4, overlap_allreduce=True,
+                            quantize_from_first_step=False)      # ref: translation_models/model.py:184,243
         batches = [synthetic_token_batch(per_gpu, dev, seed=1000 * rank + i) for i in range(2)]
         desc = ('multi30k-shaped synthetic tokens (len 20..50, V_src 18000, V_tgt 10000), 2-layer LSTM 500/500 with input '
                 'feeding + general attention (22 tensors, 28.8 M), teacher of the same shape, word-level KD 0.3 NLL + 0.7 KL; '
@@ -277,10 +322,12 @@ def dp_config_steps_per_sec(kind, dev, rank, n_gpus, distributed, steps=10, warm
     return out
 
 
-def diffquant_steps_per_sec(dev, steps=8, warmup=2, batch=100):
+def diffquant_steps_per_sec(dev, rank=0, n_gpus=1, distributed=False, steps=8, warmup=2, batch=100):
     """BASELINE configs[2]: CIFAR10 WideResNet-16-22 student (60 tensors, 82.7 M parameters), 2-bit
-    (k = 4 points) non-uniform differentiable quantization, bucket 256, 1 GPU: steps/sec of the
-    optimize_quantization_points loop with the per-step quantizer cost broken out."""
+    (k = 4 points) non-uniform differentiable quantization, bucket 256: steps/sec of the
+    optimize_quantization_points loop with the per-step quantizer cost broken out.  Quoted on 1 GPU;
+    at N > 1 it runs data parallel, exchanging only the ntensors x k point gradients."""
+    import torch.distributed as dist
     from harness import models
     from harness.diffquant import DiffQuantTrainer
     from harness.distill import synthetic_batch
@@ -289,15 +336,25 @@ def diffquant_steps_per_sec(dev, steps=8, warmup=2, batch=100):
     tr = DiffQuantTrainer(models.WideResNet(16, 22), dev, num_points=4, bucket_size=256, lr=1e-5, mode='multi')
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
-    x, y = synthetic_batch(batch, dev, seed=11)
+    x, y = synthetic_batch(batch, dev, seed=11 + 1000 * rank)
     for _ in range(warmup):
         tr.step(x, y)
     torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step(x, y)
     torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
     phases = {}
 
     def timed(name, fn, reps=5):
@@ -315,6 +372,8 @@ def diffquant_steps_per_sec(dev, steps=8, warmup=2, batch=100):
                       'percentile init, KD loss vs the unquantized model, SGD on the points; batch %d synthetic CIFAR10-shaped'
                       % (nparams / 1e6, batch),
             'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2), 'steps': steps,
+            'n_gpus': n_gpus, 'per_gpu_batch': batch, 'samples_per_sec': round(steps * batch * n_gpus / dt, 1),
+            'exchanged_bytes_per_step': int(tr.points_grad.numel() * 4) if tr.exchange else 0,
             'setup_s': round(setup_s, 2), 'phases': phases,
             'reference_cpu_quantizer_note': 'reference per-step quantizer cost on this model, CPU path: ~2.5 s per 16 Mi-element '
                                             'tensor (BASELINE.md section 3); here the 60-tensor assign + point-gradient pair is the '
@@ -340,22 +399,45 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-distill', action='store_true', help='skip the distilled-training steps/sec leg')
     ap.add_argument('--no-diffquant', action='store_true', help='skip the WideResNet differentiable-quantization leg')
+    ap.add_argument('--no-dp-configs', action='store_true', help='skip the ImageNet-shaped and seq2seq steps/sec legs')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
     args = ap.parse_args()
+
+    from harness import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, RCCL over xGMI
+        if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+            raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible'
+                             % (args.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        sys.stdout.flush()
+        raise SystemExit(launch.run_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # QD_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-reduce) even with a single rank
-    distributed = world > 1 or os.environ.get('QD_FORCE_DIST') == '1'
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d\n'
+                         % (args.gpus, world, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if distributed:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    distributed = world > 1                  # the timed region's barriers: only where there is somebody to wait for
+    rccl_error = None
+    if launch.under_launcher():
         dist.init_process_group('nccl', device_id=dev)        # "nccl" is RCCL on ROCm
-    n_gpus = world if distributed else 1
+    else:
+        # single process: still a (one-rank) RCCL group, and QD_FORCE_DIST=1 makes the harness issue its
+        # collectives in it, so that the all-reduce path of the steps/sec legs is executed and timed on this box
+        try:
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % launch.free_port(), rank=0, world_size=1,
+                                    device_id=dev)
+            os.environ['QD_FORCE_DIST'] = '1'
+        except Exception as e:                                 # noqa: BLE001 -- keep the headline measurement
+            rccl_error = '%s: %s' % (type(e).__name__, e)
+    n_gpus = world
+    rccl_world_size = dist.get_world_size() if dist.is_initialized() else None
 
     import quantization
     from quantized_distillation_amd import _lib
@@ -409,6 +491,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, event_ms = float(t[0]), float(t[1])
 
+    # the same measurement over >= 200 launches whatever --steps says (the driver's --steps 20 region is 1.8 ms)
+    ext_n = max(200, args.steps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(ext_n):
+        step(i)
+    e1.record()
+    torch.cuda.synchronize()
+    ext_us = e0.elapsed_time(e1) * 1e3 / ext_n
+
     # reference point on this very GPU: torch's own device-to-device copy of the same 256 MiB tensors
     ya = torch.empty_like(xs[0])
     for _ in range(3):
@@ -425,12 +518,14 @@ def main():
     # cpu_baseline leg (rank 0, N=1 only): the oracle is timed on the host cores and, in the same leg,
     # used as the checker of the GPU result computed above (bit-exact comparison)
     parity = None
+    parity_ref = None
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         q, sf = quantization.uniformQuantization(xs[0], LEVELS, bucket_size=BUCKET)
         try:
             cpu = cpu_baseline(x_host, q.cpu().numpy(), sf.alpha.cpu().numpy().reshape(-1))
             parity = cpu.pop('gpu_result_bit_exact')
+            parity_ref = cpu.pop('gpu_result_bit_exact_vs_reference', None)
         except Exception as e:                                    # noqa: BLE001  (keep the headline; say what failed)
             import traceback
             sys.stderr.write(traceback.format_exc())
@@ -452,13 +547,15 @@ def main():
         del live[:], xs[1:]
         torch.cuda.empty_cache()
         distill = leg(distill_steps_per_sec, dev, rank, n_gpus, distributed)
-        if n_gpus == 1 and not args.no_diffquant:
+        if not args.no_diffquant:
             torch.cuda.empty_cache()
-            distill['diffquant_wrn'] = leg(diffquant_steps_per_sec, dev)
-        # configs[3] is quoted on 8 GPUs, configs[4] on 4: run them where BASELINE.json places them
-        if n_gpus == 8 or os.environ.get('QD_BENCH_CFG4') == '1':
+            distill['diffquant_wrn'] = leg(diffquant_steps_per_sec, dev, rank, n_gpus, distributed)
+        # configs[3] is quoted on 8 GPUs and configs[4] on 4; both fit one GPU, so they are timed at every N
+        # (weak scaling: per-GPU batch fixed) and the driver's --gpus 8 / --gpus 4 runs give BASELINE's placements
+        if not args.no_dp_configs:
+            torch.cuda.empty_cache()
             distill['imagenet_resnet18k_dp'] = leg(dp_config_steps_per_sec, 'imagenet', dev, rank, n_gpus, distributed)
-        if n_gpus == 4 or os.environ.get('QD_BENCH_CFG5') == '1':
+            torch.cuda.empty_cache()
             distill['nmt_lstm_dp'] = leg(dp_config_steps_per_sec, 'nmt', dev, rank, n_gpus, distributed)
 
     # RCCL writes a version banner to the C-level stdout, which is block-buffered when piped and would
@@ -466,7 +563,7 @@ def main():
     # is the last thing on stdout
     import ctypes
     ctypes.CDLL(None).fflush(None)
-    if distributed:
+    if dist.is_initialized():
         dist.barrier()
     if rank == 0:
         bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM
@@ -491,6 +588,10 @@ def main():
                 'bound': 'hbm', 'kernel': 'k_bucket_vec<MODE_QDQ,16,4>',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': load_pmc_traffic(),
+                'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on a '
+                                  'builder box (committed file, NOT measured in this run)',
+                'extended': {'launches': ext_n, 'avg_launch_us': round(ext_us, 3),
+                             'frac': round(bytes_per_launch / (ext_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)},
                 'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
                 'timing': 'HIP events on the launch stream around the %d timed launches (includes inter-launch gaps)' % args.steps,
                 'torch_d2d_copy_GBps': round(copy_gbps, 1),      # torch's own copy of the same bytes, same box (a hand-written NT copy reaches 6.3-6.5 TB/s: profiles/r01_kbench.txt)
@@ -498,10 +599,12 @@ def main():
             'cpu_baseline': cpu,
             'distill': distill,
             'parity_bit_exact_vs_oracle': parity,
+            'parity_bit_exact_vs_reference': parity_ref,
+            'rccl_world_size': rccl_world_size, 'rccl_error': rccl_error,
             'device': torch.cuda.get_device_name(dev),
         }
         print(json.dumps(out), flush=True)
-    if distributed:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -23,6 +23,7 @@ import quantization
 import quantization.help_functions as qhf
 
 from . import models
+from .flat import broadcast_from_rank0, force_collectives
 
 
 class DiffQuantTrainer(object):
@@ -63,6 +64,8 @@ class DiffQuantTrainer(object):
             self.fns.append(quantization.nonUniformQuantization_variable(
                 bucket_size=bucket_size, pre_process_tensors=True, tensor=w))                  # ref: :507-509
         self.points.grad = self.points_grad
+        # identical replicas: the points (and the frozen weights they were initialised from) come from rank 0
+        broadcast_from_rank0(self.points)
         self.mode = mode
         if mode == 'multi':
             # persistent, pointer-stable buffers: the student's weights and gradients become views of
@@ -79,7 +82,9 @@ class DiffQuantTrainer(object):
             self.mt = MultiTensorDiffQuant([self.teacher_params[i] for i in self.slots], qs, gs, self.k, bucket_size)
         opts = dict(momentum=momentum, nesterov=nesterov) if momentum != 0 else {}
         self.opt = torch.optim.SGD([self.points], lr=lr, **opts)                                # ref: :482-484
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if ready else 1
+        self.exchange = ready and (self.world > 1 or force_collectives())
 
     def _assign_counts(self, batches, counts):
         """Gradient 2-norms under the plain loss -> points per tensor (ref: conv_forward_model.py:424-448)."""
@@ -126,9 +131,10 @@ class DiffQuantTrainer(object):
         self.quantize()
         loss = self.forward_backward(images, labels)
         self.point_gradients()
-        if self.world > 1:                               # exchange only ntensors*k floats
+        if self.exchange:                                # exchange only ntensors*k floats
             dist.all_reduce(self.points_grad)
-            self.points_grad.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.points_grad.mul_(1.0 / self.world)
         self.opt.step()
         self.points.copy_(torch.sort(self.points, dim=1)[0])                                    # ref: :550-551
         return loss

@@ -19,17 +19,36 @@ and applied to the full-precision masters.  mode='per_tensor' keeps the referenc
 import torch
 
 import quantization
+from quantized_distillation_amd import ste
 from quantized_distillation_amd.multi_tensor import MultiTensorQuantizer
 
 from . import models
-from .flat import FlatLayout, GradSynchronizer
+from .flat import FlatLayout, GradSynchronizer, broadcast_from_rank0
+
+STYLES = ('none', 'truncated', 'complicated')       # ref: conv_forward_model.py:213-229
 
 
 class DistillTrainer(object):
     def __init__(self, student, teacher, device, num_bits=4, bucket_size=256, lr=1e-3, momentum=0.9,
                  weight_decay=2.2e-4, nesterov=True, quantize_first_and_last_layer=True, mode='multi',
                  backprop_quantization_style='none', grad_chunks=1, overlap_allreduce=False, loss_fn=None,
-                 clip_norm=None, teacher_stream=False):
+                 clip_norm=None, teacher_stream=False, estimate_quant_grad_every=1, quantize_from_first_step=True):
+        """backprop_quantization_style: 'none' (pure STE), 'truncated' (clamp the quantized masters to
+        [-1, 1] before quantizing and zero the gradient where |w| > 1) or 'complicated' (bucket-aware
+        STE, K7) -- ref: conv_forward_model.py:213-229,240-266; anything else raises as the reference
+        does (:228-229).  estimate_quant_grad_every=E: quantize every E-th step only, the steps in
+        between run on the full-precision weights (ref: :286,:320-323).  quantize_from_first_step:
+        the CNN loop's counter starts at 1, so the first batch is quantized (ref: :198); the seq2seq
+        loop's starts at 0, so its first batch is NOT (ref: translation_models/model.py:184,243) --
+        pass False for that loop."""
+        style = 'none' if backprop_quantization_style is None else str(backprop_quantization_style).lower()
+        if style not in STYLES:
+            raise ValueError('The specified backprop_quantization_style not recognized')      # ref: :228-229
+        if style == 'complicated' and bucket_size is None:
+            raise NotImplementedError('Right now the code does not work with bucket_size None.'
+                                      ' Not hard to modify though')                           # ref: quant_functions.py:332-334
+        if mode not in ('multi', 'per_tensor'):
+            raise ValueError("mode must be 'multi' or 'per_tensor'")
         self.device = device
         # optional: the teacher forward (needs neither the quantized weights nor the student) on its own HIP
         # stream beside quantize + student forward, joined before the KD loss.  Measured on the CIFAR step:
@@ -42,7 +61,10 @@ class DistillTrainer(object):
         self.s = 2 ** num_bits                                   # ref: conv_forward_model.py:209-211
         self.bucket_size = bucket_size
         self.mode = mode
-        self.style = backprop_quantization_style
+        self.style = style
+        self.every = max(1, int(estimate_quant_grad_every))
+        self._since = 1 if quantize_from_first_step else 0       # step_since_last_grad_quant_estimation
+        self._quantized_step = False
         params = list(self.student.parameters())
         self.params = params
         n = len(params)
@@ -55,6 +77,19 @@ class DistillTrainer(object):
         grads = layout.views(self.flat_grad)
         for m, p in zip(self.masters, params):
             m.copy_(p.data)
+        # replicas must start identical: only gradients are exchanged afterwards (nn.DataParallel
+        # re-broadcasts from GPU 0 every step, ref: resnet34_doublefilters.py:69-70)
+        broadcast_from_rank0(self.flat_master, *[b for b in self.student.buffers() if b.is_floating_point()])
+        # contiguous runs of quantized parameters in the flat buffers: what the clamp / gradient-mask /
+        # un-quantized-step copies work on (first/last parameters excluded, ref: :237-239)
+        self.qranges = []
+        for i in range(n):
+            if self.quantized[i]:
+                a, b = layout.offsets[i], layout.end(i)
+                if self.qranges and self.qranges[-1][1] == a:
+                    self.qranges[-1] = (self.qranges[-1][0], b)
+                else:
+                    self.qranges.append((a, b))
         if mode == 'multi':
             self.flat_shadow = torch.zeros(layout.total, device=device)
             shadows = layout.views(self.flat_shadow)
@@ -80,19 +115,46 @@ class DistillTrainer(object):
 
     # ------------------------------------------------------------------ pieces of a step
     def quantize(self):
+        """Quantized weights for this step's forward/backward (ref: :235-247); the masters are only
+        touched by the 'truncated' clamp, which the reference applies to p.data in place before
+        quantizing, i.e. to the full-precision weights that the state_dict still references."""
+        if self.style == 'truncated':
+            for a, b in self.qranges:                            # ref: :240-241 -- quantized parameters only
+                ste.clamp_(self.flat_master[a:b], 1.0)
         if self.mode == 'multi':
-            if self.style == 'truncated':
-                self.flat_master.clamp_(-1, 1)                   # ref: :240-241
             self.mt.quantize(check_pointers=False)
         else:                                                    # the reference's loop shape, :235-247
             for i, p in enumerate(self.params):
                 if self.quantized[i]:
                     p.data = quantization.uniformQuantization(self.masters[i], self.s, bucket_size=self.bucket_size)[0]
+        self._quantized_step = True
+
+    def skip_quantize(self):
+        """A step between two quantized-gradient estimates (estimate_quant_grad_every > 1, or the
+        seq2seq loop's first batch): forward/backward on the full-precision weights."""
+        if self.mode == 'multi':
+            for a, b in self.qranges:
+                self.flat_shadow[a:b].copy_(self.flat_master[a:b])
+        self._quantized_step = False
 
     def restore(self):
         if self.mode != 'multi':                                 # ref: :302 load_state_dict
             for i, p in enumerate(self.params):
                 p.data = self.masters[i]
+
+    def backward_quant(self):
+        """backward_quant_weights_model (ref: :249-266): runs after the weights have been restored and
+        the gradient exchanged, before optimizer.step() (:314-318)."""
+        if self.style == 'none' or not self._quantized_step:
+            return
+        if self.style == 'truncated':                            # ref: :263-264 p.grad[p.data.abs() > 1] = 0
+            for a, b in self.qranges:
+                ste.truncated_ste_(self.flat_grad[a:b], self.flat_master[a:b], 1.0)
+        else:                                                    # 'complicated', ref: :265-266 -> quant_functions.py:319-406
+            grads = self.layout.views(self.flat_grad)
+            for i in range(len(self.params)):
+                if self.quantized[i]:
+                    ste.ste_bucket_backward(self.masters[i], grads[i], self.bucket_size, self.s, out=grads[i])
 
     def forward_backward(self, *batch):
         self.flat_grad.zero_()
@@ -109,12 +171,21 @@ class DistillTrainer(object):
     def step(self, *batch):
         if self._graph_fb is not None:
             return self._step_graph(*batch)
-        self.quantize()
+        quantize_now = self._since >= self.every                 # ref: :286 / translation_models/model.py:243
+        if quantize_now:
+            self.quantize()
+        else:
+            self.skip_quantize()
         loss = self.forward_backward(*batch)
-        self.restore()
+        if quantize_now:
+            self.restore()
         self.sync.sync()
         self.clip()
+        self.backward_quant()
         self.opt.step()
+        if quantize_now:
+            self._since = 0                                      # ref: :320-323
+        self._since += 1
         return loss
 
     # ------------------------------------------------------------------ hipGraph replay of the step
@@ -126,6 +197,8 @@ class DistillTrainer(object):
         update.  The gradient all-reduce stays between the two replays (eager RCCL call), so the
         distributed step is  A.replay(); all_reduce; B.replay().  Only for mode='multi'."""
         assert self.mode == 'multi', 'graph capture needs the persistent-shadow (multi) mode'
+        assert self.style == 'none' and self.every == 1 and self._since >= 1, \
+            'graph capture covers the plain every-step STE loop only'
         self.side = None                                 # one captured stream; the graph orders the kernels itself
         self._sx, self._sy = images.clone(), labels.clone()
         side = torch.cuda.Stream()

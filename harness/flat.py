@@ -1,6 +1,8 @@
 """Flat fp32 buffers for master weights, quantized shadows and gradients, and the data-parallel
 gradient synchroniser.  Pure torch (device-agnostic), so the multi-process logic is testable on
 CPU with gloo."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -23,80 +25,164 @@ class FlatLayout(object):
     def views(self, flat):
         return [flat[o:o + n].view(s) for o, n, s in zip(self.offsets, self.numels, self.shapes)]
 
+    def end(self, i):
+        """One past the last element of slot i including its alignment padding."""
+        return self.offsets[i + 1] if i + 1 < len(self.offsets) else self.total
+
+
+def force_collectives():
+    """QD_FORCE_DIST=1: issue the collectives even in a single-rank group, so that the RCCL call
+    path (communicator, stream ordering, async handles) is executed on a one-GPU box."""
+    return os.environ.get('QD_FORCE_DIST') == '1'
+
 
 class GradSynchronizer(object):
     """Data-parallel gradient exchange: all-reduce (sum) of the flat fp32 gradient buffer, then a
     scale by 1/world -- the MI355X-native stand-in for nn.DataParallel's reduce-to-GPU0 +
-    broadcast.  Over RCCL/xGMI on GPUs ("nccl" backend), over gloo in the CPU
-    tests.
+    broadcast (ref: resnet34_doublefilters.py:69-70,81-82, translation_models/model.py:47-48).
+    Over RCCL/xGMI on GPUs ("nccl" backend), over gloo in the CPU tests.
 
     chunks == 1: ONE all-reduce of the whole buffer after backward (small models).
-    chunks  > 1: the buffer is cut at parameter boundaries into `chunks` contiguous pieces; with
-    attach() every piece is all-reduced asynchronously AS SOON AS the gradients of all its
-    parameters have been accumulated, i.e. overlapped with the rest of backward (autograd
-    produces gradients roughly in reverse parameter order, so the last piece goes first).
+    chunks  > 1 without attach(): the buffer is cut into `chunks` equal pieces, all launched
+    asynchronously after backward.
+    attach(): OVERLAP mode.  Every parameter gets a post-accumulate-grad hook.  The first
+    backward only RECORDS the order in which gradients become ready (rank 0's order is
+    broadcast so that every rank forms the same plan); the arrival sequence is then cut into
+    `chunks` groups of about equal bytes, and from the second step on a group's ranges are
+    all-reduced asynchronously as soon as its last gradient has been accumulated, i.e.
+    overlapped with the rest of backward.  Forming the groups from the observed order matters:
+    parameters()[0] of the reference's ConvolForwardNet is the OUTPUT layer (ref:
+    conv_forward_model.py:124), whose gradient arrives first -- groups cut in parameter order
+    would put it together with the first conv layer, whose gradient arrives last.
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large pieces keep every link busy
     without paying the per-collective latency of hundreds of per-tensor reductions."""
 
-    def __init__(self, flat_grad, group=None, chunks=1):
+    def __init__(self, flat_grad, group=None, chunks=1, force=None):
         self.flat_grad = flat_grad
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        force = force_collectives() if force is None else force
+        self.active = ready and (self.world > 1 or force)
         n = flat_grad.numel()
         self.chunks = max(1, min(chunks, n))
         step = -(-n // self.chunks)
         self.bounds = [(i, min(i + step, n)) for i in range(0, n, step)]
+        self.collectives_issued = 0
+        # overlap mode state
+        self._layout = None
+        self._numels = None
+        self._order = None            # arrival order being recorded during the first backward
+        self._group_of = None         # param index -> group
+        self._group_ranges = None     # group -> [(a, b), ...]
         self._pending = None
+        self._group_sizes = None
+        self._launched = None
         self._handles = []
-        self._launched = []
 
+    # ------------------------------------------------------------------ overlap mode
     def attach(self, params, layout):
         """Overlap mode: register post-accumulate hooks on `params` (laid out by `layout`)."""
-        total_params = len(params)
-        per = -(-total_params // self.chunks)
-        groups = [list(range(i, min(i + per, total_params))) for i in range(0, total_params, per)]
-        self.bounds = []
-        for g in groups:
-            a = layout.offsets[g[0]]
-            last = g[-1]
-            b = layout.offsets[last + 1] if last + 1 < total_params else layout.total
-            self.bounds.append((a, b))
-        self._group_sizes = [len(g) for g in groups]
-        self._pending = list(self._group_sizes)
-        self._launched = [False] * len(groups)
-        if self.world == 1:
+        self._layout = layout
+        self._numels = list(layout.numels)
+        self._order = []
+        if not self.active:
             return
-        for c, g in enumerate(groups):
-            for i in g:
-                params[i].register_post_accumulate_grad_hook(lambda _p, c=c: self._ready(c))
+        for i, p in enumerate(params):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._ready(i))
 
-    def _launch(self, c):
-        a, b = self.bounds[c]
-        self._handles.append(dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
-        self._launched[c] = True
-
-    def _ready(self, c):
+    def _ready(self, i):
+        if self._group_of is None:
+            self._order.append(i)
+            return
+        c = self._group_of[i]
         self._pending[c] -= 1
         if self._pending[c] == 0 and not self._launched[c]:
             self._launch(c)
 
+    def _plan(self):
+        """Cut the recorded arrival order into groups of ~equal bytes; merge each group's
+        parameters into contiguous ranges of the flat buffer."""
+        nparams = len(self._numels)
+        order = list(dict.fromkeys(self._order))                  # first arrival of each parameter
+        order += [i for i in range(nparams) if i not in set(order)]     # parameters that got no gradient
+        if self.world > 1:                                        # every rank must cut the same groups
+            t = torch.tensor(order, dtype=torch.int64, device=self.flat_grad.device)
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
+            order = [int(v) for v in t.tolist()]
+        total = float(sum(self._numels)) or 1.0
+        groups, acc, cur = [], 0.0, []
+        for i in order:
+            cur.append(i)
+            acc += self._numels[i]
+            if acc >= total * (len(groups) + 1) / self.chunks and len(groups) < self.chunks - 1:
+                groups.append(cur)
+                cur = []
+        if cur:
+            groups.append(cur)
+        self._group_of = {}
+        self._group_ranges = []
+        for c, g in enumerate(groups):
+            ranges = []
+            for i in sorted(g):
+                self._group_of[i] = c
+                a, b = self._layout.offsets[i], self._layout.end(i)
+                if ranges and ranges[-1][1] == a:
+                    ranges[-1] = (ranges[-1][0], b)
+                else:
+                    ranges.append((a, b))
+            self._group_ranges.append(ranges)
+        self._group_sizes = [len(g) for g in groups]
+        self._pending = list(self._group_sizes)
+        self._launched = [False] * len(groups)
+        self.bounds = [r for ranges in self._group_ranges for r in ranges]
+
+    def _all_reduce_async(self, a, b):
+        self.collectives_issued += 1
+        return dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _launch(self, c):
+        for a, b in self._group_ranges[c]:
+            self._handles.append(self._all_reduce_async(a, b))
+        self._launched[c] = True
+
+    # ------------------------------------------------------------------ per step
     def sync(self):
-        if self.world == 1:
+        if not self.active:
             return
-        if self._pending is None:                       # no hooks: everything now
-            self._handles = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True) for a, b in self.bounds]
+        if self._layout is None:                        # no hooks: everything now
+            self._handles = [self._all_reduce_async(a, b) for a, b in self.bounds]
+        elif self._group_of is None:                    # first step of overlap mode: plan, reduce un-overlapped
+            self._plan()
+            for c in range(len(self._group_ranges)):
+                self._launch(c)
         else:
-            for c in range(len(self.bounds)):           # pieces whose parameters got no gradient this step
+            for c in range(len(self._group_ranges)):    # groups whose parameters got no gradient this step
                 if not self._launched[c]:
                     self._launch(c)
-            self._pending = list(self._group_sizes)
-            self._launched = [False] * len(self.bounds)
         for h in self._handles:
             h.wait()
         self._handles = []
-        self.flat_grad.mul_(1.0 / self.world)
+        if self._group_of is not None:
+            self._pending = list(self._group_sizes)
+            self._launched = [False] * len(self._group_ranges)
+        if self.world > 1:
+            self.flat_grad.mul_(1.0 / self.world)
+
+
+def broadcast_from_rank0(*tensors, group=None):
+    """Make every replica start from rank 0's values (weights, buffers, quantization points).
+    nn.DataParallel re-replicates from GPU 0 every step (ref: resnet34_doublefilters.py:69-70);
+    here the replicas are kept identical by construction (same gradient, same update), so one
+    broadcast at setup is what it takes."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size(group) == 1 and not force_collectives():
+        return
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    for t in tensors:
+        dist.broadcast(t, src=src, group=group)
 
 
 def shard_range(total, rank, world):

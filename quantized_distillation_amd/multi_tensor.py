@@ -34,6 +34,8 @@ class MultiTensorQuantizer(object):
             if not t.is_contiguous():
                 raise ValueError('multi-tensor quantization needs contiguous tensors')
         self.device = self.inputs[0].device
+        if any(t.device != self.device for t in self.inputs):
+            raise ValueError('all tensors of a multi-tensor launch must live on one device')
         self.outputs = list(outputs) if outputs is not None else [torch.empty_like(t) for t in self.inputs]
         if len(self.outputs) != len(self.inputs):
             raise ValueError('need one output per input')
@@ -73,11 +75,16 @@ class MultiTensorQuantizer(object):
                 if t.data_ptr() != px or o.data_ptr() != pq:
                     self._plan()       # storage moved (e.g. p.data was rebound): rebuild the table
                     break
-        if self._tiles > 0 and self.bucket_size is None:
+        if self._tiles <= 0:
+            return self.outputs
+        if _lib.on_other_device(self._table):        # launch with the tensors' device current
+            with torch.cuda.device(self.device):
+                return self.quantize(check_pointers=False)
+        if self.bucket_size is None:
             _lib.check(_lib.load().qd_multi_uniform_global_f32(
                 self._table.data_ptr(), len(self.inputs), self._tiles, self.s, self.alpha_beta.data_ptr(),
                 self._scratch.data_ptr(), self._scratch.numel() * 4, _lib.stream_ptr(self.device)))
-        elif self._tiles > 0:
+        else:
             _lib.check(_lib.load().qd_multi_uniform_f32(self._table.data_ptr(), len(self.inputs), self._tiles,
                                                         self.bucket_size, self.s, _lib.stream_ptr(self.device)))
         return self.outputs
@@ -103,6 +110,9 @@ class MultiTensorDiffQuant(object):
         if not 1 <= num_points <= 64:
             raise ValueError('the multi-tensor diff-quant path supports 1..64 points per tensor')
         self.k, self.bucket_size = int(num_points), bucket_size
+        # OWNING references: the device table below holds raw pointers into these tensors, so they are kept
+        # alive here for the lifetime of the object.  A caller that rebinds `p.grad` (zero_grad(set_to_none=True))
+        # does not free them; backward() then reads the buffers given HERE, which is what check_pointers guards.
         self.outputs, self.grads = list(outputs), list(grads)
         self.device = tensors[0].device
         self.scalings, self.scaled, self.indices = [], [], []
@@ -112,11 +122,19 @@ class MultiTensorDiffQuant(object):
                 _lib.require_device_f32(other)
                 if other.numel() != t.numel() or not other.is_contiguous():
                     raise ValueError('outputs / grads must be contiguous and match the tensors in size')
+                if other.device != self.device:
+                    raise ValueError('all tensors of a multi-tensor launch must live on one device')
+            if t.device != self.device:
+                raise ValueError('all tensors of a multi-tensor launch must live on one device')
             sf = ScalingFunction('linear', False, False, bucket_size)
             u = sf.scale_down(t).view(-1)[0:t.numel()].contiguous()
             self.scalings.append(sf)
             self.scaled.append(u)
             self.indices.append(torch.empty(t.numel(), dtype=torch.uint8, device=self.device))
+        self._plan()
+
+    def _plan(self):
+        bucket_size = self.bucket_size
         n = len(self.scaled)
         lib = _lib.load()
         host = (_lib.QdDiffQuantDesc * n)()
@@ -136,11 +154,36 @@ class MultiTensorDiffQuant(object):
         self._table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
         self._scratch = torch.empty(max(1, self._blocks * self.k), dtype=torch.float32, device=self.device)
         self.n_tensors = n
+        self._ptrs = [(o.data_ptr(), g.data_ptr()) for o, g in zip(self.outputs, self.grads)]
+
+    def rebind(self, outputs=None, grads=None):
+        """Point the device table at new output / gradient buffers (e.g. after the caller re-allocated
+        its gradients) -- one small H2D copy."""
+        if outputs is not None:
+            self.outputs = list(outputs)
+        if grads is not None:
+            self.grads = list(grads)
+        for u, o, g in zip(self.scaled, self.outputs, self.grads):
+            for other in (o, g):
+                _lib.require_device_f32(other)
+                if other.numel() != u.numel() or not other.is_contiguous() or other.device != self.device:
+                    raise ValueError('outputs / grads must be contiguous, on the same device and match the tensors in size')
+        self._plan()
+
+    def _check(self):
+        for (po, pg), o, g in zip(self._ptrs, self.outputs, self.grads):
+            if o.data_ptr() != po or g.data_ptr() != pg:
+                self._plan()           # a held tensor's storage was swapped (set_, resize_): rebuild the table
+                break
 
     def forward(self, points):
         """points: [ntensors, k] fp32 device tensor, each row sorted.  Writes outputs[i] in place."""
         if points.shape != (self.n_tensors, self.k) or not points.is_contiguous():
             raise ValueError('points must be a contiguous [ntensors, k] tensor')
+        if _lib.on_other_device(self._table):
+            with torch.cuda.device(self.device):
+                return self.forward(points)
+        self._check()
         _lib.check(_lib.load().qd_multi_nearest_f32(self._table.data_ptr(), self.n_tensors, self._tiles, self.bucket_size,
                                                     points.data_ptr(), self.k, _lib.stream_ptr(self.device)))
         return self.outputs
@@ -149,6 +192,10 @@ class MultiTensorDiffQuant(object):
         """grad of the points from the gradient buffers given at construction: [ntensors, k]."""
         if out is None:
             out = torch.empty(self.n_tensors, self.k, dtype=torch.float32, device=self.device)
+        if _lib.on_other_device(self._table):
+            with torch.cuda.device(self.device):
+                return self.backward(out)
+        self._check()
         _lib.check(_lib.load().qd_multi_point_grad_f32(self._table.data_ptr(), self.n_tensors, self._blocks,
                                                        self.bucket_size, self.k, out.data_ptr(), self._scratch.data_ptr(),
                                                        self._scratch.numel() * 4, _lib.stream_ptr(self.device)))

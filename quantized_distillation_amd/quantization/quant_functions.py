@@ -19,6 +19,18 @@ from .. import _lib
 _STOCHASTIC_CALLS = [0]
 
 
+def next_stochastic_seed(peek=False):
+    """Seed of the next stochastic-rounding launch.  The reference draws torch.rand on the host
+    (ref: :185-186); here the draws come from an in-kernel counter-based generator keyed by this
+    seed and the element index.  The seed is derived from the CURRENT DEVICE's default generator
+    seed (so torch.manual_seed / torch.cuda.manual_seed control it) and a per-process call counter
+    (so successive calls draw different numbers)."""
+    calls = _STOCHASTIC_CALLS[0] + 1
+    if not peek:
+        _STOCHASTIC_CALLS[0] = calls
+    return (torch.cuda.initial_seed() * 0x9E3779B97F4A7C15 + calls) & 0xFFFFFFFFFFFFFFFF
+
+
 def _bucket_arg(bucket_size):
     return 0 if bucket_size is None else int(bucket_size)
 
@@ -43,8 +55,10 @@ class ScalingFunction(object):
     bucket, int64) are computed ON DEMAND from the retained input the first time they are read:
     nothing on the per-step path reads them, and materialising them eagerly as the reference
     does (:85-90) would add 16 B/bucket of traffic plus index tracking to the hot kernel.  They
-    are therefore only valid while the tensor passed to `scale_down` has not been modified
-    (with `modify_in_place=True` they are computed eagerly, before the data is overwritten).
+    are therefore only available while the tensor passed to `scale_down` has not been modified
+    (checked through the tensor's version counter: reading them afterwards raises instead of
+    returning stale indices; with `modify_in_place=True` they are computed eagerly, before the
+    data is overwritten).
     """
 
     def __init__(self, type_scaling, max_element, subtract_mean, bucket_size, modify_in_place=False):
@@ -77,7 +91,8 @@ class ScalingFunction(object):
         self.tensor_sign = None
         self._idx_min_rows = None
         self._idx_max_rows = None
-        self._arg_source = None        # (tensor, mean_buf) kept for the lazy arg-min/max
+        self._arg_source = None        # tensor kept for the lazy arg-min/max
+        self._arg_version = None       # its ._version when it was scaled: a later in-place write invalidates the lazy indices
         self._mean_buf = None
 
     # ------------------------------------------------------------------ helpers
@@ -134,6 +149,7 @@ class ScalingFunction(object):
         self._idx_min_rows = None
         self._idx_max_rows = None
         self._arg_source = tensor
+        self._arg_version = tensor._version
         if overwritten:                # the data is about to be replaced: materialise now
             self._compute_arg_indices()
 
@@ -141,6 +157,12 @@ class ScalingFunction(object):
         t = self._arg_source
         if t is None:
             return
+        if t._version != self._arg_version:
+            # the reference computes the indices eagerly inside scale_down (ref: :85-90); here they are
+            # taken from the tensor on first access, which is only the same thing while it is unchanged
+            raise RuntimeError('idx_min_rows / idx_max_rows were requested after the tensor passed to scale_down / the '
+                               'quantizer was modified in place: they are computed lazily from that tensor. Read them '
+                               'before modifying it (or pass a copy).')
         n = t.numel()
         nb, _ = _geometry(n, self.bucket_size)
         out = torch.empty(2, nb, dtype=torch.int64, device=t.device)
@@ -284,8 +306,7 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     clamp, me = scaling_function._clamp_args()
     seed = 0
     if stochastic_rounding:
-        _STOCHASTIC_CALLS[0] += 1
-        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _STOCHASTIC_CALLS[0]) & 0xFFFFFFFFFFFFFFFF
+        seed = next_stochastic_seed()
     if n > 0:
         if nb == 1:                       # only the single-bucket path needs the reduction scratch
             ws = _lib.workspace(tensor.device)
@@ -349,7 +370,7 @@ def _nearest(x_ptr, prescaled, points, assign_mode, n, bucket_size, alpha, beta,
     q = torch.empty(n, dtype=torch.float32, device=device)
     idx = torch.empty(n, dtype=torch.int64 if idx_bytes == 8 else torch.uint8, device=device)
     if n > 0:
-        if bucket_size is None or n < bucket_size:      # single bucket: the reduction scratch is needed
+        if _geometry(n, bucket_size)[0] == 1:           # single bucket (incl. n == bucket_size): the reduction scratch is needed
             ws = _lib.workspace(device)
             ws_ptr, ws_len = ws.data_ptr(), ws.numel()
         else:

@@ -41,11 +41,26 @@ def _worker(rank, world, port, chunks, out_dir):
     loss.backward()
     sync = GradSynchronizer(flat_grad, chunks=abs(chunks))
     if chunks < 0:                                         # negative = overlap mode: hooks fire during backward
-        flat_grad.zero_()
         sync.attach(params, layout)
-        net.zero_grad(set_to_none=False)
-        loss = torch.nn.functional.cross_entropy(net(images[lo:hi]), labels[lo:hi])
-        loss.backward()
+        # step 1 records the order in which gradients arrive and reduces un-overlapped; from step 2 on every
+        # group is all-reduced from the hook of its last gradient, while backward is still running
+        for step in range(3):
+            flat_grad.zero_()
+            loss = torch.nn.functional.cross_entropy(net(images[lo:hi]), labels[lo:hi])
+            issued = sync.collectives_issued
+            loss.backward()
+            if step == 0:
+                assert sync.collectives_issued == issued, 'the first backward only records the arrival order'
+            else:
+                assert sync.collectives_issued > issued, 'groups must be launched from inside backward'
+            if step < 2:
+                sync.sync()
+        # the plan: out_layer (parameters()[0:2]) receives its gradient FIRST, so it belongs to the first group
+        assert sync._group_of[0] == 0 and sync._group_of[1] == 0
+        assert len(sync._group_ranges) == abs(chunks)
+        covered = sorted(r for ranges in sync._group_ranges for r in ranges)
+        assert covered[0][0] == 0 and covered[-1][1] == layout.total
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), 'ranges must tile the flat buffer'
     sync.sync()
     torch.save(flat_grad, os.path.join(out_dir, 'grad_rank%d.pt' % rank))
     dist.barrier()

@@ -1,0 +1,99 @@
+"""Parity on the parameter SHAPE LISTS of all five BASELINE.json configs:
+  cfg 0/1  CIFAR10 ConvolForwardNet student             22 tensors,  1.0 M   4-bit uniform, bucket 256
+  cfg 2    CIFAR10 WideResNet-16-22                     60 tensors, 82.7 M   2-bit non-uniform (k = 4 points)
+           (ref: cifar10_wideResNet.py:91; largest tensor (1408,1408,3,3) = 17.8 M elements)
+  cfg 3    resnet18(k=1.5), ImageNet shapes             62 tensors, 25.9 M   4-bit, bucket 256,
+           quantize_first_and_last_layer=False (ref: resnet34_doublefilters.py:77)
+  cfg 4    2-layer LSTM seq2seq                         22 tensors, 28.8 M   4-bit, bucket 256
+           (ref: onmt/standard_options.py:19-35: (18000,500), (2000,1000), ...)
+Every tensor of every list goes through the multi-tensor launch AND the per-tensor API and must be
+bit-identical to the C oracle (itself pinned to the reference by the golden vectors)."""
+import numpy as np
+import pytest
+import torch
+
+import quantization
+from harness import models
+from oracle import oracle_c
+from quantized_distillation_amd.multi_tensor import MultiTensorDiffQuant, MultiTensorQuantizer
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _weights(name):
+    """The model's own initialisation (weight-like values: xavier/normal fans, zero biases, BN ones) with a
+    deterministic perturbation so that biases / BN affine tensors are not constant."""
+    torch.manual_seed(1234)
+    net = {'cifar_student': models.student, 'wrn_16_22': lambda: models.WideResNet(16, 22),
+           'resnet18_k1.5': lambda: models.ResNetK((2, 2, 2, 2), 1.5), 'lstm_seq2seq': models.Seq2SeqLSTM}[name]()
+    g = torch.Generator().manual_seed(99)
+    out = []
+    for p in net.parameters():
+        t = p.detach().clone()
+        if t.dim() <= 1:
+            t = t + 0.01 * torch.randn(t.shape, generator=g)
+        out.append(t.contiguous())
+    return out
+
+
+EXPECT = {'cifar_student': (22, 800000), 'wrn_16_22': (60, 1408 * 1408 * 9), 'resnet18_k1.5': (62, 768 * 768 * 9),
+          'lstm_seq2seq': (22, 18000 * 500)}
+
+
+@pytest.mark.parametrize('name,first_last', [('cifar_student', True), ('cifar_student', False), ('wrn_16_22', True),
+                                             ('resnet18_k1.5', False), ('lstm_seq2seq', True)])
+@pytest.mark.parametrize('bucket', [256, None])
+def test_uniform_4bit_on_config_shape_list(name, first_last, bucket):
+    host = _weights(name)
+    ntens, biggest = EXPECT[name]
+    assert len(host) == ntens and max(t.numel() for t in host) == biggest
+    n = len(host)
+    slots = [i for i in range(n) if first_last or (i != 0 and i != n - 1)]      # ref: conv_forward_model.py:237-239
+    dev = [host[i].to(DEV) for i in slots]
+    mt = MultiTensorQuantizer(dev, 16, bucket)
+    outs = mt.quantize()
+    for j, i in enumerate(slots):
+        want = oracle_c.uniform_quantize(host[i].numpy(), 16, bucket, want_idx=False, want_lev=False)
+        got_multi = outs[j].cpu().numpy()
+        assert np.array_equal(got_multi, want['q']), (name, i, tuple(host[i].shape), 'multi-tensor')
+        q, sf = quantization.uniformQuantization(dev[j], 16, bucket_size=bucket)           # the reference's loop shape
+        assert np.array_equal(q.cpu().numpy(), want['q']), (name, i, tuple(host[i].shape), 'per-tensor')
+        assert np.array_equal(sf.alpha.cpu().numpy().reshape(-1), want['alpha']), (name, i)
+        assert np.array_equal(sf.beta.cpu().numpy().reshape(-1), want['beta']), (name, i)
+        assert q.shape == host[i].shape
+    if not first_last:
+        assert len(slots) == n - 2
+
+
+def test_nonuniform_2bit_on_wrn_shape_list():
+    """cfg 2: k = 4 points per tensor from the percentile initialisation, assignment by the midpoint
+    rule (the per-step call), point gradient -- multi-tensor sweeps and per-tensor API vs the C oracle."""
+    import quantization.help_functions as qhf
+    host = _weights('wrn_16_22')
+    dev = [t.to(DEV) for t in host]
+    k, bucket = 4, 256
+    scaling = quantization.ScalingFunction('linear', False, False, bucket, False)
+    points = torch.stack([qhf.initialize_quantization_points(t, scaling, k) for t in dev]).contiguous()
+    outs = [torch.empty_like(t) for t in dev]
+    g_host = [torch.randn(t.shape, generator=torch.Generator().manual_seed(7 + i)) * 1e-3 for i, t in enumerate(host)]
+    grads = [g.to(DEV) for g in g_host]
+    mt = MultiTensorDiffQuant(dev, outs, grads, k, bucket)
+    mt.forward(points)
+    gp = mt.backward().cpu().numpy().astype(np.float64)
+    pts_host = points.cpu().numpy()
+    for i, t in enumerate(host):
+        want = oracle_c.nonuniform_quantize(t.numpy(), pts_host[i], bucket, mode='midpoint')
+        assert np.array_equal(outs[i].cpu().numpy(), want['q']), (i, tuple(t.shape), 'multi-tensor forward')
+        assert np.array_equal(mt.indices[i].cpu().numpy(), want['idx'].reshape(-1).astype(np.uint8)), (i, 'indices')
+        wg, absum = oracle_c.point_grad(g_host[i].numpy(), want['idx'], want['alpha'], bucket, k)
+        assert np.all(np.abs(gp[i] - wg) <= 2e-6 * absum + 1e-30), (i, 'point gradient', gp[i], wg)
+        if t.numel() in (1408 * 1408 * 9, 16 * 3 * 9, 1408, 10 * 1408):        # per-tensor API on a spread of shapes
+            fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=dev[i])
+            q = fn.forward(None, points[i])
+            assert np.array_equal(q.cpu().numpy(), want['q']), (i, 'per-tensor forward')
+            _, gpt = fn.backward(grads[i])
+            assert np.all(np.abs(gpt.cpu().numpy().astype(np.float64) - wg) <= 2e-6 * absum + 1e-30), (i, 'per-tensor grad')
+            qd, idxd, _ = quantization.nonUniformQuantization(dev[i], points[i], bucket_size=bucket)
+            wd = oracle_c.nonuniform_quantize(t.numpy(), pts_host[i], bucket, mode='distance')
+            assert np.array_equal(qd.cpu().numpy(), wd['q']) and np.array_equal(idxd.cpu().numpy(), wd['idx']), (i, 'distance rule')

@@ -56,13 +56,110 @@ def test_model_computes_on_quantized_weights_and_updates_masters():
     assert not np.array_equal(q, big.cpu().numpy())
 
 
-def test_truncated_style_clamps_masters():
-    t = make('multi', style='truncated')
-    t.flat_master.mul_(50.0)
-    t.quantize()                                            # ref: conv_forward_model.py:240-241 clamps before quantizing
-    assert float(t.flat_master.abs().max()) <= 1.0
+def _reference_style_step(t, x, y, style, first_last):
+    """The reference's step (ref: cnn_models/conv_forward_model.py:235-318) restated with torch ops and the oracle-checked
+    per-tensor API on a deep copy of trainer `t`'s state; returns the flat master after optimizer.step()."""
+    import copy
+    import quantization
+    net = copy.deepcopy(t.student)
+    params = list(net.parameters())
+    for p, m in zip(params, t.masters):
+        p.data = m.clone()
+        p.grad = None
+    n = len(params)
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=2.2e-4)
+    fns = [quantization.uniformQuantization_variable(16, bucket_size=256) for _ in params]
+    saved = [p.data for p in params]                                              # state_dict(): references, not copies
+    for i, p in enumerate(params):
+        if not first_last and (i == 0 or i == n - 1):
+            continue
+        if style == 'truncated':
+            p.data.clamp_(-1, 1)
+        p.data = fns[i].forward(p.data) if style == 'complicated' else quantization.uniformQuantization(p.data, 16, bucket_size=256)[0]
+    from harness.distill import cnn_kd_loss_fn
+    cnn_kd_loss_fn(net, t.teacher, x, y).backward()
+    for p, m in zip(params, saved):                                               # load_state_dict
+        p.data = m
+    for i, p in enumerate(params):
+        if not first_last and (i == 0 or i == n - 1):
+            continue
+        if style == 'truncated':
+            p.grad.data[p.data.abs() > 1] = 0
+        elif style == 'complicated':
+            p.grad.data = fns[i].backward(p.grad.data)
+    opt.step()
+    return [p.data for p in params]
+
+
+@pytest.mark.parametrize('style', ['none', 'truncated', 'complicated'])
+@pytest.mark.parametrize('mode', ['multi', 'per_tensor'])
+@pytest.mark.parametrize('first_last', [True, False])
+def test_backprop_styles_match_the_reference_loop(style, mode, first_last):
+    """'truncated' clamps only the QUANTIZED masters (in both modes) and masks the gradient; 'complicated' runs
+    the bucket-aware STE (K7) between the gradient exchange and optimizer.step()."""
+    torch.backends.cudnn.deterministic = True
+    t = make(mode, first_last=first_last, style=style)
+    t.flat_master.mul_(3.0)                              # push weights beyond [-1, 1] so that the clamp matters
+    x, y = synthetic_batch(16, DEV, seed=5)
+    want = _reference_style_step(t, x, y, style, first_last)
+    before = t.flat_master.clone()
+    t.step(x, y)
+    n = len(t.params)
+    for i, (m, w) in enumerate(zip(t.masters, want)):
+        assert torch.allclose(m, w, rtol=2e-4, atol=2e-6), (style, mode, i, float((m - w).abs().max()))
+    if style == 'truncated':
+        for i, m in enumerate(t.masters):
+            big = float(m.abs().max()) > 1.01
+            if not first_last and i in (0, n - 1):
+                continue                                  # not quantized: never clamped (may or may not exceed 1)
+            assert not big, 'quantized masters are clamped to [-1, 1]'
+        if not first_last:
+            assert float(before[t.layout.offsets[0]:t.layout.end(0)].abs().max()) > 1.0
+            assert float(t.masters[0].abs().max()) > 1.0, 'the excluded first tensor must NOT be clamped'
+    assert not torch.equal(t.flat_master, before)
+
+
+def test_unknown_style_raises_like_the_reference():
+    with pytest.raises(ValueError, match='backprop_quantization_style not recognized'):
+        make('multi', style='fancy')
+    with pytest.raises(NotImplementedError):
+        make('multi', style='complicated', bucket=None)
+
+
+def test_first_batch_not_quantized_in_the_seq2seq_loop_and_quantize_every_e_steps():
+    """ref: translation_models/model.py:184,243 (counter starts at 0: first batch un-quantized) and
+    conv_forward_model.py:286,320-323 (estimate_quant_grad_every)."""
+    torch.manual_seed(0)
+    t = DistillTrainer(models.student(), models.teacher(), DEV, num_bits=4, bucket_size=256, mode='multi',
+                       quantize_from_first_step=False)
     x, y = synthetic_batch(8, DEV, seed=1)
-    assert torch.isfinite(t.step(x, y))
+    t.step(x, y)
+    assert not t._quantized_step
+    t.step(x, y)
+    assert t._quantized_step
+    big = [i for i, m in enumerate(t.masters) if m.numel() == 800000][0]
+    assert not torch.equal(t.params[big].data, t.masters[big])
+    torch.manual_seed(0)
+    e = DistillTrainer(models.student(), models.teacher(), DEV, num_bits=4, bucket_size=256, mode='multi',
+                       estimate_quant_grad_every=3)
+    seen = []
+    for _ in range(7):
+        e.step(x, y)
+        seen.append(e._quantized_step)
+    assert seen == [False, False, True, False, False, True, False]
+
+
+def test_ste_python_api_matches_torch_ops():
+    from quantized_distillation_amd import ste
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(100003, generator=g) * 1.5).to(DEV)
+    gr = torch.randn(100003, generator=g).to(DEV)
+    want_g = gr.clone()
+    want_g[w.abs() > 1] = 0
+    assert torch.equal(ste.truncated_ste_(gr.clone(), w), want_g)
+    assert torch.equal(ste.clamp_(w.clone()), w.clamp(-1, 1))
+    with pytest.raises(RuntimeError):
+        ste.clamp_(torch.zeros(4))                          # CPU tensor: no CPU path
 
 
 def test_graph_replay_matches_eager():

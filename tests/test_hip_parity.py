@@ -224,7 +224,7 @@ def test_stochastic_rounding_bit_exact_on_every_kernel_path():
              (10007, 3, 4), (10007, 513, 16), (4096, 128, 2), (50, 256, 16)]
     for n, bucket, s in cases:
         x = rng.randn(n).astype(np.float32)
-        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + qf._STOCHASTIC_CALLS[0] + 1) & 0xFFFFFFFFFFFFFFFF
+        seed = qf.next_stochastic_seed(peek=True)
         q, sf = quantization.uniformQuantization(dev(x), s, stochastic_rounding=True, bucket_size=bucket)
         draws = onp.philox4x32_7_uniform(seed, n)
         nb, row, padded = onp.bucket_geometry(n, bucket)
@@ -643,3 +643,42 @@ def test_api_calls_under_hipgraph_capture():
         rm = oc.nonuniform_quantize(x0, pts, 256, 'midpoint')     # fn was pre-processed on x0: its u is resident
         want, absum = oc.point_grad(gv, rm['idx'], rm['alpha'], 256, k)
         assert np.all(np.abs(host(gp).astype(np.float64) - want) <= 4e-6 * absum + 1e-30)
+
+
+# ------------------------------------------------------------------------------ round-2 boundary fixes
+def test_lazy_arg_indices_raise_after_the_source_was_modified():
+    """idx_min_rows / idx_max_rows are taken lazily from the tensor given to scale_down (the reference computes them
+    eagerly, quant_functions.py:85-90): reading them after an in-place write to that tensor must raise, never
+    return indices of the NEW data."""
+    x = dev(np.random.RandomState(5).randn(5000).astype(np.float32))
+    sf = quantization.ScalingFunction('linear', False, False, 256)
+    sf.scale_down(x)
+    x.mul_(-1.0)                                   # arg-min and arg-max swap places
+    with pytest.raises(RuntimeError, match='modified in place'):
+        sf.idx_min_rows
+    # untouched source: fine, and equal to the oracle's first-occurrence indices
+    y = dev(np.random.RandomState(6).randn(5000).astype(np.float32))
+    q, sf2 = quantization.uniformQuantization(y, 16, bucket_size=256)
+    want = onp.uniform_quantize(host(y), 16, 256)
+    assert np.array_equal(host(sf2.idx_min_rows).reshape(-1), want['imin'])
+    assert np.array_equal(host(sf2.idx_max_rows).reshape(-1), want['imax'])
+    # read first, modify later: the materialised indices stay available
+    z = dev(np.random.RandomState(7).randn(5000).astype(np.float32))
+    _, sf3 = quantization.uniformQuantization(z, 16, bucket_size=256)
+    keep = host(sf3.idx_max_rows).copy()
+    z.zero_()
+    assert np.array_equal(host(sf3.idx_max_rows), keep)
+
+
+@pytest.mark.parametrize('n', [16385, 20000, 70001])
+def test_nonuniform_single_bucket_of_exactly_bucket_size(n):
+    """numel == bucket_size is ONE bucket (help_functions.py:67-94) and takes the single-bucket kernel, which needs
+    the reduction scratch above 16 Ki elements (round-1 advisor finding: NULL workspace -> QD_ERR_WORKSPACE_TOO_SMALL)."""
+    x = np.random.RandomState(n).randn(n).astype(np.float32)
+    pts = np.sort(np.random.RandomState(1).rand(5)).astype(np.float32)
+    q, idx, sf = quantization.nonUniformQuantization(dev(x), torch.from_numpy(pts), bucket_size=n)
+    want = onp.nonuniform_quantize(x, pts, n)
+    assert np.array_equal(host(q), want['q']) and np.array_equal(host(idx), want['idx'])
+    fn = quantization.nonUniformQuantization_variable(bucket_size=n, pre_process_tensors=True, tensor=dev(x))
+    q2 = fn.forward(None, torch.from_numpy(pts).to(DEV))
+    assert np.array_equal(host(q2), onp.nonuniform_quantize(x, pts, n, 'midpoint')['q'])

@@ -125,25 +125,43 @@ def test_percentile_from_sorted_is_numpy_exact():
 
 
 def test_checkpoint_formats_roundtrip(tmp_path):
-    """The two on-disk formats the reference's evaluation scripts read (cifar10_test.py:265-270,
-    model_manager.py:182-190): plain pickles of Python lists/dicts + torch.save state dicts."""
+    """The on-disk formats the reference's evaluation scripts read (cifar10_test.py:265-270,
+    model_manager.py:182-190,214-249,321-347): plain pickles of Python lists/dicts + torch.save state dicts.
+    tests/test_checkpoints_reference.py opens the same files with the reference's own ModelManager."""
     import pickle
     from harness import checkpoints, models
     net = models.student()
     pts = torch.sort(torch.rand(22, 4), dim=1)[0]
+    pts[3, 2:] = float('inf')                          # a tensor that got 2 points from the automatic allocation
     base = str(tmp_path / 'quant_points_2bits')
     checkpoints.save_quantization_points(base, pts, {'predictionAccuracy': [0.5], 'numEpochsTrained': 1}, net.state_dict())
     with open(base, 'rb') as f:                        # exactly what the reference's reader does
         raw_points, info = pickle.load(f)
     assert isinstance(raw_points, list) and len(raw_points) == 22 and isinstance(raw_points[0][0], float)
+    assert len(raw_points[3]) == 2 and len(raw_points[0]) == 4
     assert info['numEpochsTrained'] == 1
     p2, _, sd = checkpoints.load_quantization_points(base)
-    assert np.allclose(np.array(p2, dtype=np.float32), pts.numpy())
+    assert np.allclose(np.array(p2[0], dtype=np.float32), pts[0].numpy())
     net.load_state_dict(sd)
-    run = str(tmp_path / 'student1')
-    checkpoints.save_training_run(run, net, {'numBits': 4, 'bucket_size': 256}, {'lossSaved': [1.0]})
-    sd2, args, info2 = checkpoints.load_training_run(run)
-    assert args['numBits'] == 4 and info2['lossSaved'] == [1.0] and set(sd2) == set(net.state_dict())
+
+    store = checkpoints.RunStore(str(tmp_path / 'manager'), 'cifar10', create=True)
+    store.add_new_model('student', str(tmp_path / 'student'), {'spec': {'conv': [75, 50]}, 'useBatchNorm': True})
+    args = {'numBits': 4, 'bucket_size': 256, 'loss_function': torch.nn.functional.cross_entropy, 'teacher_model': net,
+            'learning_rate_style': 'generic', 'quantize_first_and_last_layer': False}
+    assert store.append_run('student', net.state_dict(), args, {'numEpochsTrained': 0}) is None    # aborted run: nothing saved
+    path = store.append_run('student', net.state_dict(), args, {'numEpochsTrained': 2, 'lossSaved': [1.0, 0.5]})
+    assert path.endswith('student1') and store.get_num_training_runs('student') == 1
+    again = checkpoints.RunStore(str(tmp_path / 'manager'))
+    meta = again.load_metadata('student')
+    assert isinstance(meta, list) and len(meta) == 2 and all(isinstance(m, dict) for m in meta)
+    assert meta[0]['numBits'] == 4 and meta[0]['quantize_first_and_last_layer'] is False
+    assert meta[0]['loss_function'].startswith('Name: cross_entropy. Repr: <function cross_entropy')
+    assert meta[0]['teacher_model'].startswith('ConvNet(')            # nn.Module: callable without __name__ -> repr
+    assert meta[1]['lossSaved'] == [1.0, 0.5]
+    assert again.load_metadata('student', 0)[0]['spec'] == repr({'conv': [75, 50]})     # a dict value is repr()-ed
+    assert set(again.load_model_state_dict('student')) == set(net.state_dict())
+    with pytest.raises(ValueError):
+        checkpoints.RunStore(str(tmp_path / 'manager'), 'x', create=True)
 
 
 def test_hyperspherical_helpers_match_reference():

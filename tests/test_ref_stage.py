@@ -1,0 +1,57 @@
+"""oracle/ref_stage.py: the reference's own quantization package, compiled to bytecode under the
+git-ignored oracle/_ref/, is what bench.py times as `cpu_baseline` (kind "reference") on the GPU
+box.  Here: it loads without disturbing this repository's `quantization` package, and it IS the
+reference -- its outputs equal the golden vectors (which gen_golden.py produced from the sources)
+and the oracle's."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+from oracle import ref_stage
+
+pytestmark = pytest.mark.skipif(not (ref_stage.is_staged() or os.path.exists(ref_stage.REF_ROOT)),
+                                reason='nothing staged and no reference checkout')
+
+
+def test_staged_reference_loads_beside_the_product_package():
+    import quantization as product
+    refq = ref_stage.load()
+    assert refq is not None and refq is not product
+    assert os.path.abspath(refq.__file__).startswith(ref_stage.STAGE_DIR)
+    import sys
+    assert sys.modules['quantization'] is product, 'the product package must stay registered under its name'
+    assert refq.uniformQuantization.__module__ == 'quantization.quant_functions'
+    assert not os.path.exists(os.path.join(ref_stage.PKG_DIR, 'quant_functions.py')), 'bytecode only: no source is copied'
+    man = ref_stage.manifest()
+    assert man and set(man['files']) == set(ref_stage.FILES)
+
+
+def test_staged_reference_reproduces_golden_vectors(golden_uniform):
+    refq = ref_stage.load()
+    G = golden_uniform
+    checked = 0
+    for i, c in enumerate(G.meta):
+        if c.get('stochastic') or c.get('type', 'linear') != 'linear':
+            continue
+        x = torch.from_numpy(G.arr('u', i, 'x').copy())
+        kw = dict(bucket_size=c.get('bucket'), max_element=c.get('max_element', False),
+                  subtract_mean=c.get('subtract_mean', False))
+        q, sf = refq.uniformQuantization(x, c['s'], **kw)
+        assert np.array_equal(q.numpy(), G.arr('u', i, 'q')), i
+        checked += 1
+        if checked >= 60:
+            break
+    assert checked >= 30
+
+
+@pytest.mark.parametrize('n,bucket,s', [(100003, 256, 16), (4097, None, 4), (1000, 33, 16), (5, 256, 2)])
+def test_staged_reference_equals_oracle(n, bucket, s):
+    refq = ref_stage.load()
+    x = torch.randn(n, generator=torch.Generator().manual_seed(n))
+    q, sf = refq.uniformQuantization(x, s, bucket_size=bucket)
+    want = onp.uniform_quantize(x.numpy(), s, bucket)
+    assert np.array_equal(q.numpy(), want['q'])
+    assert np.array_equal(sf.alpha.numpy().reshape(-1), want['alpha'].reshape(-1))
