@@ -104,6 +104,28 @@ def load():
     return _lib
 
 
+_glue = None
+GLUE_PATH = os.path.join(_HERE, '_qd_glue.so')
+
+
+def glue():
+    """The CPython/ATen binding of the per-call entry points (csrc/qd_torch_glue.cpp -> _qd_glue.so): one native
+    call does output allocation + current stream + the C-ABI launch.  Fails loudly when it has not been built."""
+    global _glue
+    if _glue is None:
+        load()
+        if not os.path.exists(GLUE_PATH):
+            raise QdLibraryMissing(
+                'quantized_distillation_amd: %s is missing. Build it first: '
+                'python -c "import __graft_entry__ as g; g.build()". There is no fallback binding.' % GLUE_PATH)
+        import torch  # noqa: F401  (libtorch must be loaded before the extension)
+        from . import _qd_glue
+        if _qd_glue.abi_version() != 1:
+            raise RuntimeError('_qd_glue.so is linked against ABI version %d, expected 1' % _qd_glue.abi_version())
+        _glue = _qd_glue
+    return _glue
+
+
 def check(code):
     if code != 0:
         msg = load().qd_error_string(code)

@@ -1,0 +1,320 @@
+// _qd_glue -- the per-call binding of the hot entry points of libqd_hip.so for Python/PyTorch callers.
+//
+// The drop-in boundary is the C ABI of include/qd_hip.h (raw device pointers, no torch types).  The
+// reference's training loops call the quantizer once per parameter tensor per step
+// (cnn_models/conv_forward_model.py:235-247: 22-110 calls per step, most of them on tiny tensors), so
+// for those loops the cost of a call is the HOST cost of getting from a torch.Tensor to that ABI: with
+// ctypes that was 11-13 us per call (two torch allocations, ~16 argument conversions, a Python-side
+// ScalingFunction).  This file is the same binding written against the CPython C API and ATen directly:
+// unpack the tensor, allocate the outputs from torch's caching allocator, take torch's current HIP
+// stream, call the C ABI -- nothing else.  It contains no kernels and no arithmetic; every entry point
+// forwards to exactly one qd_* function (two when subtract_mean adds qd_mean_f32).
+//
+// PyTorch is used for device memory and the current stream only.
+#include <Python.h>
+
+#include <ATen/ATen.h>
+#include <ATen/hip/EmptyTensor.h>
+#include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/Exceptions.h>
+#include <torch/csrc/autograd/python_variable.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "qd_hip.h"
+
+namespace {
+
+struct Workspace {
+    int device;
+    void* stream;
+    at::Tensor buf;
+};
+std::vector<Workspace> g_workspaces;   // one scratch buffer per (device, stream): kernels on a stream are ordered
+size_t g_workspace_bytes = 0;
+
+inline at::Tensor empty_f32(c10::IntArrayRef sizes, const c10::Device& dev) {
+    return at::Tensor(at::detail::empty_cuda(sizes, at::kFloat, dev, c10::nullopt));
+}
+inline at::Tensor empty_of(c10::IntArrayRef sizes, at::ScalarType t, const c10::Device& dev) {
+    return at::Tensor(at::detail::empty_cuda(sizes, t, dev, c10::nullopt));
+}
+
+void* workspace_for(const c10::Device& dev, void* stream, size_t* bytes) {
+    for (auto& w : g_workspaces)
+        if (w.device == dev.index() && w.stream == stream) {
+            *bytes = g_workspace_bytes;
+            return w.buf.data_ptr();
+        }
+    if (g_workspace_bytes == 0) g_workspace_bytes = qd_workspace_bytes();
+    at::Tensor buf = empty_of({static_cast<int64_t>(g_workspace_bytes)}, at::kByte, dev);
+    g_workspaces.push_back({static_cast<int>(dev.index()), stream, buf});
+    *bytes = g_workspace_bytes;
+    return buf.data_ptr();
+}
+
+void check_rc(int rc) {
+    if (rc != 0) {
+        const char* msg = qd_error_string(rc);
+        throw std::runtime_error(std::string("qd_hip: ") + (msg ? msg : "?") + " (code " + std::to_string(rc) + ")");
+    }
+}
+
+const at::Tensor& tensor_arg(PyObject* o, const char* what) {
+    if (!THPVariable_Check(o)) {
+        PyErr_Format(PyExc_TypeError, "%s must be a torch.Tensor, got %s", what, Py_TYPE(o)->tp_name);
+        throw python_error();
+    }
+    return THPVariable_Unpack(o);
+}
+
+void require_device_f32(const at::Tensor& t, const char* what) {
+    if (!t.is_cuda())
+        throw std::runtime_error(std::string("quantized_distillation_amd: ") + what +
+                                 " must live on a HIP device (got " + t.device().str() + "); this package has no CPU path");
+    if (t.scalar_type() != at::kFloat) {
+        PyErr_Format(PyExc_TypeError, "%s must be float32 (the reference path is fp32-only), got %s", what,
+                     c10::toString(t.scalar_type()));
+        throw python_error();
+    }
+}
+
+inline int64_t num_buckets(int64_t n, int64_t bucket) { return (bucket <= 0 || n < bucket) ? 1 : (n + bucket - 1) / bucket; }
+
+// uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place) -> (q, ab, mean | None)
+//   ab: [2, nb, 1] (bucket > 0) or [2, 1] (bucket == 0): row 0 = alpha, row 1 = beta, shaped as the reference's
+//   min/max(keepdim=True) results (quant_functions.py:85-92).  One qd_uniform_f32 launch.
+PyObject* glue_uniform(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    HANDLE_TH_ERRORS
+    if (nargs != 9) {
+        PyErr_SetString(PyExc_TypeError, "uniform() takes 9 positional arguments");
+        return nullptr;
+    }
+    const at::Tensor& x0 = tensor_arg(args[0], "tensor");
+    require_device_f32(x0, "tensor");
+    const long levels = PyLong_AsLong(args[1]);
+    const long long bucket = PyLong_AsLongLong(args[2]);
+    const int clamp = PyObject_IsTrue(args[3]);
+    const double max_element = PyFloat_AsDouble(args[4]);
+    const int stochastic = PyObject_IsTrue(args[5]);
+    const unsigned long long seed = PyLong_AsUnsignedLongLongMask(args[6]);
+    const int subtract_mean = PyObject_IsTrue(args[7]);
+    const int in_place = PyObject_IsTrue(args[8]);
+    if (PyErr_Occurred()) return nullptr;
+
+    at::Tensor x = x0;
+    if (!x.is_contiguous()) {
+        if (in_place) {
+            PyErr_SetString(PyExc_ValueError, "modify_in_place=True needs a contiguous tensor");
+            return nullptr;
+        }
+        x = x.contiguous();
+    }
+    const c10::Device dev = x.device();
+    c10::hip::OptionalHIPGuard guard;
+    if (dev.index() != c10::hip::current_device()) guard.set_index(dev.index());
+    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+
+    const int64_t n = x.numel();
+    const int64_t nb = num_buckets(n, bucket);
+    at::Tensor q = in_place ? x : at::Tensor(at::detail::empty_cuda(x.sizes(), at::kFloat, dev, c10::nullopt));
+    at::Tensor ab = bucket > 0 ? empty_f32({2, nb, 1}, dev) : empty_f32({2, 1}, dev);
+    at::Tensor mean;
+    float* mean_ptr = nullptr;
+    if (n > 0) {
+        void* ws = nullptr;
+        size_t ws_bytes = 0;
+        if (nb == 1 || subtract_mean) ws = workspace_for(dev, stream, &ws_bytes);
+        if (subtract_mean) {
+            mean = empty_f32({1}, dev);
+            mean_ptr = mean.data_ptr<float>();
+            check_rc(qd_mean_f32(x.data_ptr<float>(), n, mean_ptr, ws, ws_bytes, stream));
+        }
+        float* abp = ab.data_ptr<float>();
+        check_rc(qd_uniform_f32(x.data_ptr<float>(), q.data_ptr<float>(), n, bucket, static_cast<int>(levels), abp, abp + nb,
+                                nullptr, mean_ptr, clamp, static_cast<float>(max_element), stochastic, seed,
+                                nb == 1 ? ws : nullptr, nb == 1 ? ws_bytes : 0, stream));
+    } else if (subtract_mean) {
+        mean = empty_f32({1}, dev);
+    }
+    PyObject* out = PyTuple_New(3);
+    PyTuple_SET_ITEM(out, 0, THPVariable_Wrap(q));
+    PyTuple_SET_ITEM(out, 1, THPVariable_Wrap(ab));
+    if (mean.defined()) {
+        PyTuple_SET_ITEM(out, 2, THPVariable_Wrap(mean));
+    } else {
+        Py_INCREF(Py_None);
+        PyTuple_SET_ITEM(out, 2, Py_None);
+    }
+    return out;
+    END_HANDLE_TH_ERRORS
+}
+
+// nearest(x, prescaled, points, assign_mode, n, bucket, alpha, beta, mean | None, clamp, max_element, idx_bytes)
+//   -> (q [n], idx [n] int64 | uint8).  alpha/beta are outputs when prescaled == 0, inputs otherwise.
+//   One qd_nearest_point_f32 launch.
+PyObject* glue_nearest(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    HANDLE_TH_ERRORS
+    if (nargs != 12) {
+        PyErr_SetString(PyExc_TypeError, "nearest() takes 12 positional arguments");
+        return nullptr;
+    }
+    const at::Tensor& x = tensor_arg(args[0], "tensor");
+    const int prescaled = PyObject_IsTrue(args[1]);
+    const at::Tensor& points = tensor_arg(args[2], "points");
+    const long assign_mode = PyLong_AsLong(args[3]);
+    const long long n = PyLong_AsLongLong(args[4]);
+    const long long bucket = PyLong_AsLongLong(args[5]);
+    const at::Tensor& alpha = tensor_arg(args[6], "alpha");
+    const at::Tensor& beta = tensor_arg(args[7], "beta");
+    const float* mean_ptr = args[8] == Py_None ? nullptr : tensor_arg(args[8], "mean").data_ptr<float>();
+    const int clamp = PyObject_IsTrue(args[9]);
+    const double max_element = PyFloat_AsDouble(args[10]);
+    const long idx_bytes = PyLong_AsLong(args[11]);
+    if (PyErr_Occurred()) return nullptr;
+    require_device_f32(x, "tensor");
+    require_device_f32(points, "points");
+    if (!x.is_contiguous() || !points.is_contiguous() || x.numel() < n) {
+        PyErr_SetString(PyExc_ValueError, "nearest(): tensor and points must be contiguous and hold n elements");
+        return nullptr;
+    }
+    const c10::Device dev = x.device();
+    c10::hip::OptionalHIPGuard guard;
+    if (dev.index() != c10::hip::current_device()) guard.set_index(dev.index());
+    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    at::Tensor q = empty_f32({static_cast<int64_t>(n)}, dev);
+    at::Tensor idx = empty_of({static_cast<int64_t>(n)}, idx_bytes == 8 ? at::kLong : at::kByte, dev);
+    if (n > 0) {
+        void* ws = nullptr;
+        size_t ws_bytes = 0;
+        if (num_buckets(n, bucket) == 1) ws = workspace_for(dev, stream, &ws_bytes);
+        check_rc(qd_nearest_point_f32(x.data_ptr<float>(), prescaled, points.data_ptr<float>(), static_cast<int>(points.numel()),
+                                      static_cast<int>(assign_mode), q.data_ptr<float>(), idx.data_ptr(),
+                                      static_cast<int>(idx_bytes), n, bucket, alpha.data_ptr<float>(), beta.data_ptr<float>(),
+                                      mean_ptr, clamp, static_cast<float>(max_element), ws, ws_bytes, stream));
+    }
+    PyObject* out = PyTuple_New(2);
+    PyTuple_SET_ITEM(out, 0, THPVariable_Wrap(q));
+    PyTuple_SET_ITEM(out, 1, THPVariable_Wrap(idx));
+    return out;
+    END_HANDLE_TH_ERRORS
+}
+
+// point_grad(g, idx, alpha, bucket, k) -> grad_points [k].  One qd_point_grad_f32 call (two launches inside).
+PyObject* glue_point_grad(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    HANDLE_TH_ERRORS
+    if (nargs != 5) {
+        PyErr_SetString(PyExc_TypeError, "point_grad() takes 5 positional arguments");
+        return nullptr;
+    }
+    const at::Tensor& g0 = tensor_arg(args[0], "grad_output");
+    const at::Tensor& idx = tensor_arg(args[1], "indices");
+    const at::Tensor& alpha = tensor_arg(args[2], "alpha");
+    const long long bucket = PyLong_AsLongLong(args[3]);
+    const long k = PyLong_AsLong(args[4]);
+    if (PyErr_Occurred()) return nullptr;
+    require_device_f32(g0, "grad_output");
+    at::Tensor g = g0.is_contiguous() ? g0 : g0.contiguous();
+    const int64_t n = g.numel();
+    if (idx.numel() != n) {
+        PyErr_SetString(PyExc_ValueError, "grad_output must have as many elements as the quantized tensor");
+        return nullptr;
+    }
+    const int idx_bytes = idx.scalar_type() == at::kLong ? 8 : 1;
+    const c10::Device dev = g.device();
+    c10::hip::OptionalHIPGuard guard;
+    if (dev.index() != c10::hip::current_device()) guard.set_index(dev.index());
+    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    at::Tensor gp = empty_f32({static_cast<int64_t>(k)}, dev);
+    size_t ws_bytes = 0;
+    void* ws = workspace_for(dev, stream, &ws_bytes);
+    check_rc(qd_point_grad_f32(g.data_ptr<float>(), idx.data_ptr(), idx_bytes, alpha.data_ptr<float>(), n, bucket,
+                               static_cast<int>(k), gp.data_ptr<float>(), ws, ws_bytes, stream));
+    return THPVariable_Wrap(gp);
+    END_HANDLE_TH_ERRORS
+}
+
+PyObject* glue_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(qd_abi_version()); }
+
+// host_cost_probe(x, levels, bucket, iters) -> (us per bare C-ABI launch, us per output allocation pair, us per launch with
+// allocation).  Measurement aid for tools/profile_api_overhead.py: where the per-call host time of uniform() goes.
+PyObject* glue_host_cost_probe(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    HANDLE_TH_ERRORS
+    if (nargs != 4) {
+        PyErr_SetString(PyExc_TypeError, "host_cost_probe() takes 4 positional arguments");
+        return nullptr;
+    }
+    const at::Tensor& x = tensor_arg(args[0], "tensor");
+    require_device_f32(x, "tensor");
+    const long levels = PyLong_AsLong(args[1]);
+    const long long bucket = PyLong_AsLongLong(args[2]);
+    const long iters = PyLong_AsLong(args[3]);
+    if (PyErr_Occurred()) return nullptr;
+    const c10::Device dev = x.device();
+    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    const int64_t n = x.numel(), nb = num_buckets(n, bucket);
+    at::Tensor q = empty_f32({n}, dev), ab = empty_f32({2, nb, 1}, dev);
+    size_t ws_bytes = 0;
+    void* ws = workspace_for(dev, stream, &ws_bytes);
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    double t_launch = 0, t_alloc = 0, t_both = 0;
+    for (long done = 0; done < iters; done += 64) {      // keep the device queue shallow: sync outside the timed parts
+        auto a = now();
+        for (int i = 0; i < 64; ++i)
+            check_rc(qd_uniform_f32(x.data_ptr<float>(), q.data_ptr<float>(), n, bucket, (int)levels, ab.data_ptr<float>(),
+                                    ab.data_ptr<float>() + nb, nullptr, nullptr, 0, 0.f, 0, 0, ws, ws_bytes, stream));
+        auto b = now();
+        t_launch += us(a, b);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        a = now();
+        for (int i = 0; i < 64; ++i) {
+            at::Tensor q2 = at::Tensor(at::detail::empty_cuda(x.sizes(), at::kFloat, dev, c10::nullopt));
+            at::Tensor ab2 = empty_f32({2, nb, 1}, dev);
+        }
+        b = now();
+        t_alloc += us(a, b);
+        a = now();
+        for (int i = 0; i < 64; ++i) {
+            at::Tensor q2 = at::Tensor(at::detail::empty_cuda(x.sizes(), at::kFloat, dev, c10::nullopt));
+            at::Tensor ab2 = empty_f32({2, nb, 1}, dev);
+            check_rc(qd_uniform_f32(x.data_ptr<float>(), q2.data_ptr<float>(), n, bucket, (int)levels, ab2.data_ptr<float>(),
+                                    ab2.data_ptr<float>() + nb, nullptr, nullptr, 0, 0.f, 0, 0, ws, ws_bytes, stream));
+        }
+        b = now();
+        t_both += us(a, b);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+    }
+    const double calls = (double)((iters + 63) / 64 * 64);
+    return Py_BuildValue("(ddd)", t_launch / calls, t_alloc / calls, t_both / calls);
+    END_HANDLE_TH_ERRORS
+}
+
+PyMethodDef methods[] = {
+    {"uniform", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_uniform)), METH_FASTCALL,
+     "uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place) -> (q, ab, mean)"},
+    {"nearest", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_nearest)), METH_FASTCALL,
+     "nearest(x, prescaled, points, assign_mode, n, bucket, alpha, beta, mean, clamp, max_element, idx_bytes) -> (q, idx)"},
+    {"point_grad", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_point_grad)), METH_FASTCALL,
+     "point_grad(g, idx, alpha, bucket, k) -> grad_points"},
+    {"host_cost_probe", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_host_cost_probe)), METH_FASTCALL,
+     "host_cost_probe(x, levels, bucket, iters) -> (launch us, allocation us, both us): host time per call"},
+    {"abi_version", glue_abi_version, METH_NOARGS, "ABI version of the libqd_hip.so this module is linked against"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyModuleDef module = {PyModuleDef_HEAD_INIT, "_qd_glue",
+                      "CPython/ATen binding of the per-call entry points of libqd_hip.so (include/qd_hip.h)", -1, methods,
+                      nullptr, nullptr, nullptr, nullptr};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit__qd_glue(void) { return PyModule_Create(&module); }

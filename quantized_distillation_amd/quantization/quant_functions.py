@@ -61,39 +61,78 @@ class ScalingFunction(object):
     data is overwritten).
     """
 
+    # Class-level defaults: an instance only stores what a call actually sets -- the per-step loops build one
+    # ScalingFunction per parameter tensor per step (ref: conv_forward_model.py:235-247), so its construction
+    # is on the host-side critical path of the drop-in.
+    tol_diff_zero = 1e-10
+    mean_tensor = None
+    original_tensor_size = None
+    norm_scaling = None
+    tensor_sign = None
+    _n = None
+    _ab = None                     # [2, nb, 1] / [2, 1]: alpha and beta in one allocation, split on first access
+    _alpha = None
+    _beta = None
+    _idx_min_rows = None
+    _idx_max_rows = None
+    _arg_source = None             # tensor kept for the lazy arg-min/max
+    _arg_version = None            # its ._version when it was scaled: a later in-place write invalidates the lazy indices
+    _mean_buf = None
+
     def __init__(self, type_scaling, max_element, subtract_mean, bucket_size, modify_in_place=False):
-        type_scaling = type_scaling.lower()
-        if type_scaling not in ('linear', 'absmax', 'absnorm'):                     # ref: :22-25
-            raise ValueError('Incorrect parameter: type of scaling must be "linear", "absMax" or "absNorm"')
-        if bucket_size is not None and (not isinstance(bucket_size, int) or isinstance(bucket_size, bool)
-                                        or bucket_size <= 0):                       # ref: :27-29
+        if type_scaling != 'linear':
+            type_scaling = type_scaling.lower()
+            if type_scaling not in ('linear', 'absmax', 'absnorm'):                 # ref: :22-25
+                raise ValueError('Incorrect parameter: type of scaling must be "linear", "absMax" or "absNorm"')
+        if bucket_size is not None and (type(bucket_size) is not int or bucket_size <= 0):
+            # (np.integer and bool are rejected as the reference's isinstance(bucket_size, int) check does, :27-29)
             raise ValueError('Bucket size must be an integer and strictly positive. '
                              'Pass None if you want to avoid using buckets')
-        if max_element is True:                                                     # ref: :31-33
-            raise ValueError('maxElementAllowed must be a number')
-        if max_element is not False and not isinstance(max_element, numbers.Number):
-            raise ValueError('maxElementAllowed must be a number')
-
+        if max_element is not False and (max_element is True or not isinstance(max_element, numbers.Number)):
+            raise ValueError('maxElementAllowed must be a number')                  # ref: :31-33
         self.type_scaling = type_scaling
         self.max_element = max_element
         self.subtract_mean = subtract_mean
         self.bucket_size = bucket_size
         self.modify_in_place = modify_in_place
-        self.tol_diff_zero = 1e-10
 
-        self.mean_tensor = None
-        self.original_tensor_size = None
-        self.original_tensor_length = None
-        self.expected_tensor_size = None
-        self.alpha = None
-        self.beta = None
-        self.norm_scaling = None
-        self.tensor_sign = None
-        self._idx_min_rows = None
-        self._idx_max_rows = None
-        self._arg_source = None        # tensor kept for the lazy arg-min/max
-        self._arg_version = None       # its ._version when it was scaled: a later in-place write invalidates the lazy indices
-        self._mean_buf = None
+    # ------------------------------------------------------------------ lazily materialised fields
+    @property
+    def alpha(self):
+        if self._alpha is None and self._ab is not None:
+            self._alpha, self._beta = self._ab.unbind(0)
+        return self._alpha
+
+    @alpha.setter
+    def alpha(self, v):
+        self._alpha = v
+
+    @property
+    def beta(self):
+        if self._beta is None and self._ab is not None:
+            self._alpha, self._beta = self._ab.unbind(0)
+        return self._beta
+
+    @beta.setter
+    def beta(self, v):
+        self._beta = v
+
+    @property
+    def original_tensor_length(self):
+        return self._n
+
+    @original_tensor_length.setter
+    def original_tensor_length(self, v):
+        self._n = v
+
+    @property
+    def expected_tensor_size(self):
+        """Shape of the bucket view (ref: :79-81, help_functions.py:67-94)."""
+        if self._n is None:
+            return None
+        if self.bucket_size is None:
+            return torch.Size([self._n])
+        return torch.Size(_geometry(self._n, self.bucket_size))
 
     # ------------------------------------------------------------------ helpers
     def _abs_kind(self):
@@ -119,10 +158,6 @@ class ScalingFunction(object):
         self.original_tensor_size = tensor.size()
         self.original_tensor_length = n
         nb, row = _geometry(n, self.bucket_size)
-        if self.bucket_size is None:
-            self.expected_tensor_size = torch.Size([n])                              # ref: :79-81
-        else:
-            self.expected_tensor_size = torch.Size([nb, row])
         if self.subtract_mean:
             self._mean_buf = torch.empty(1, dtype=torch.float32, device=tensor.device)
             if n > 0:
@@ -142,7 +177,7 @@ class ScalingFunction(object):
             ab = torch.empty(2, 1, dtype=torch.float32, device=device)
         else:
             ab = torch.empty(2, nb, 1, dtype=torch.float32, device=device)
-        self.alpha, self.beta = ab.unbind(0)
+        self._ab, self._alpha, self._beta = ab, None, None
         return ab
 
     def _note_arg_source(self, tensor, overwritten):
@@ -272,54 +307,68 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     Returns (quantized tensor of the same shape, ScalingFunction).  ref: :155-194.
 
     One fused kernel (K1) for bucketed tensors -- per-bucket min/max, alpha/beta, scale, round
-    half to even, rescale; three small launches without buckets (global reduce, fold, apply).
-    The input is left untouched unless modify_in_place=True."""
+    half to even, rescale; without buckets one kernel too when the tensor fits on chip, three
+    small launches otherwise.  The input is left untouched unless modify_in_place=True.
+
+    The call goes through the CPython/ATen binding of the C ABI (csrc/qd_torch_glue.cpp): output
+    allocation, current stream and the launch happen in one native call, and the returned
+    ScalingFunction materialises alpha / beta / the arg indices only when they are read."""
+    sf = ScalingFunction(type_of_scaling, max_element, subtract_mean, bucket_size, True)    # as the reference, :166-167
+    if int(s) != s or s < 2:
+        raise ValueError('s must be an integer >= 2')
+    if sf.type_scaling != 'linear':
+        return _uniform_abs(tensor, s, sf, stochastic_rounding, modify_in_place)
+    if modify_in_place:
+        # the arg indices are taken lazily from the input, which is about to be overwritten: materialise them first
+        _lib.require_device_f32(tensor)
+        if not tensor.is_contiguous():
+            raise ValueError('modify_in_place=True needs a contiguous tensor')
+        if subtract_mean:
+            sf.modify_in_place = True
+            with torch.cuda.device(tensor.device):
+                sf._begin(tensor)                  # the mean the indices are relative to
+        sf._n = tensor.numel()
+        with torch.cuda.device(tensor.device):
+            sf._note_arg_source(tensor, overwritten=True)
+    clamp = max_element is not False
+    q, ab, mean = _lib.glue().uniform(tensor, int(s), bucket_size or 0, clamp, float(max_element) if clamp else 0.0,
+                                      stochastic_rounding, next_stochastic_seed() if stochastic_rounding else 0,
+                                      subtract_mean, modify_in_place)
+    sf.original_tensor_size = q.shape
+    sf._n = q.numel()
+    sf._ab = ab
+    if mean is not None:
+        sf._mean_buf = mean
+        sf.mean_tensor = mean.view(())                                               # 0-dim, ref: :67
+    else:
+        sf.mean_tensor = 0                                                           # ref: :70
+    if not modify_in_place:
+        sf._arg_source = tensor if tensor.is_contiguous() else tensor.contiguous()
+        sf._arg_version = tensor._version
+    return q, sf
+
+
+def _uniform_abs(tensor, s, scaling_function, stochastic_rounding, modify_in_place):
+    """'absmax' / 'absnorm' scaling: intended math only, parity unpinned (see ScalingFunction._abs_kind)."""
     if isinstance(tensor, torch.Tensor) and _lib.on_other_device(tensor):
         with torch.cuda.device(tensor.device):
-            return uniformQuantization(tensor, s, type_of_scaling, stochastic_rounding, max_element, subtract_mean,
-                                       bucket_size, modify_in_place)
-    scaling_function = ScalingFunction(type_of_scaling, max_element, subtract_mean, bucket_size,
-                                       modify_in_place=True)                         # as the reference, :166-167
-    saved_flag = modify_in_place
+            return _uniform_abs(tensor, s, scaling_function, stochastic_rounding, modify_in_place)
+    bucket_size = scaling_function.bucket_size
     scaling_function.modify_in_place = modify_in_place      # governs _begin's contiguity rule
     tensor, n, nb, row = scaling_function._begin(tensor)
     scaling_function.modify_in_place = True
-    if int(s) != s or s < 2:
-        raise ValueError('s must be an integer >= 2')
-    if scaling_function._abs_kind() is not None:
-        if stochastic_rounding:
-            raise NotImplementedError('stochastic rounding is implemented for linear scaling only')
-        out = tensor if modify_in_place else torch.empty_like(tensor)
-        norm = torch.empty(nb, dtype=torch.float32, device=tensor.device)
-        clamp, me = scaling_function._clamp_args()
-        if n > 0:
-            ws = _lib.workspace(tensor.device)
-            _lib.check(_lib.load().qd_uniform_abs_f32(
-                tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), scaling_function._abs_kind(),
-                norm.data_ptr(), _ptr(scaling_function._mean_buf), clamp, me, ws.data_ptr(), ws.numel(),
-                _lib.stream_ptr(tensor.device)))
-        scaling_function.norm_scaling = norm.view(1) if bucket_size is None else norm.view(nb, 1)
-        return out, scaling_function
-    scaling_function._note_arg_source(tensor, overwritten=saved_flag)
-    out = tensor if modify_in_place else torch.empty_like(tensor)
-    ab = scaling_function._alloc_alpha_beta(nb, tensor.device)
-    clamp, me = scaling_function._clamp_args()
-    seed = 0
     if stochastic_rounding:
-        seed = next_stochastic_seed()
+        raise NotImplementedError('stochastic rounding is implemented for linear scaling only')
+    out = tensor if modify_in_place else torch.empty_like(tensor)
+    norm = torch.empty(nb, dtype=torch.float32, device=tensor.device)
+    clamp, me = scaling_function._clamp_args()
     if n > 0:
-        if nb == 1:                       # only the single-bucket path needs the reduction scratch
-            ws = _lib.workspace(tensor.device)
-            ws_ptr, ws_len = ws.data_ptr(), ws.numel()
-        else:
-            ws_ptr, ws_len = None, 0
-        ab_ptr = ab.data_ptr()
-        rc = _lib.load().qd_uniform_f32(
-            tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), ab_ptr, ab_ptr + 4 * nb,
-            None, _ptr(scaling_function._mean_buf), clamp, me, 1 if stochastic_rounding else 0,
-            seed, ws_ptr, ws_len, _lib.stream_ptr(tensor.device))
-        if rc != 0:
-            _lib.check(rc)
+        ws = _lib.workspace(tensor.device)
+        _lib.check(_lib.load().qd_uniform_abs_f32(
+            tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), scaling_function._abs_kind(),
+            norm.data_ptr(), _ptr(scaling_function._mean_buf), clamp, me, ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr(tensor.device)))
+    scaling_function.norm_scaling = norm.view(1) if bucket_size is None else norm.view(nb, 1)
     return out, scaling_function
 
 
@@ -365,23 +414,10 @@ def _points_on(points, device):
     return points
 
 
-def _nearest(x_ptr, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mean_buf, clamp, me,
-             device, idx_bytes):
-    q = torch.empty(n, dtype=torch.float32, device=device)
-    idx = torch.empty(n, dtype=torch.int64 if idx_bytes == 8 else torch.uint8, device=device)
-    if n > 0:
-        if _geometry(n, bucket_size)[0] == 1:           # single bucket (incl. n == bucket_size): the reduction scratch is needed
-            ws = _lib.workspace(device)
-            ws_ptr, ws_len = ws.data_ptr(), ws.numel()
-        else:
-            ws_ptr, ws_len = None, 0
-        rc = _lib.load().qd_nearest_point_f32(
-            x_ptr, prescaled, points.data_ptr(), points.numel(), assign_mode, q.data_ptr(), idx.data_ptr(),
-            idx_bytes, n, _bucket_arg(bucket_size), alpha.data_ptr(), beta.data_ptr(), _ptr(mean_buf), clamp, me,
-            ws_ptr, ws_len, _lib.stream_ptr(device))
-        if rc != 0:
-            _lib.check(rc)
-    return q, idx
+def _nearest(x, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mean_buf, clamp, me, idx_bytes):
+    """(q [n], idx [n]) -- one K4/K5 launch through the native binding (allocation + stream + launch)."""
+    return _lib.glue().nearest(x, prescaled, points, assign_mode, n, bucket_size or 0, alpha, beta, mean_buf,
+                               clamp, me, idx_bytes)
 
 
 def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
@@ -421,8 +457,8 @@ def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
         points = _points_on(listQuantizationPoints, tensor.device)
         sf._alloc_alpha_beta(nb, tensor.device)
         clamp, me = sf._clamp_args()
-        q, idx = _nearest(tensor.data_ptr(), 0, points, 0, n, bucket_size, sf.alpha, sf.beta, sf._mean_buf,
-                          clamp, me, tensor.device, 8)
+        q, idx = _nearest(tensor, False, points, 0, n, bucket_size, sf.alpha, sf.beta, sf._mean_buf,
+                          clamp, me, 8)
         if modify_in_place:
             tensor.view(-1).copy_(q)
             q = tensor
@@ -432,8 +468,7 @@ def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
     u = search_sorted_obj.scaled_tensor
     n = sf.original_tensor_length
     points = _points_on(listQuantizationPoints, u.device)
-    q, idx = _nearest(u.data_ptr(), 1, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf, 0, 0.0,
-                      u.device, 8)
+    q, idx = _nearest(u, True, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf, 0, 0.0, 8)
     return q.view(sf.original_tensor_size), idx.view(sf.original_tensor_size), sf
 
 
@@ -555,8 +590,8 @@ class nonUniformQuantization_variable(object):
             u = self.search_sorted_obj.scaled_tensor
             points = _points_on(listQuantizationPoints, u.device)
             n = sf.original_tensor_length
-            q, idx = _nearest(u.data_ptr(), 1, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf,
-                              0, 0.0, u.device, 1 if numPoints <= 256 else 8)
+            q, idx = _nearest(u, True, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf,
+                              0, 0.0, 1 if numPoints <= 256 else 8)
             q = q.view(sf.original_tensor_size)
             idx = idx.view(sf.original_tensor_size)
         else:
@@ -579,15 +614,6 @@ class nonUniformQuantization_variable(object):
         idx = self.savedForBackward.raw_indices()
         k = self.savedForBackward['numPoints']
         alpha = self.savedForBackward['scalingFactor']
-        g = grad_output.contiguous()
-        n = g.numel()
-        if idx.numel() != n:
-            raise ValueError('grad_output must have as many elements as the quantized tensor')
-        grad_points = torch.empty(k, dtype=torch.float32, device=g.device)
-        ws = _lib.workspace(g.device)
-        _lib.check(_lib.load().qd_point_grad_f32(
-            g.data_ptr(), idx.data_ptr(), 8 if idx.dtype == torch.int64 else 1, alpha.data_ptr(), n,
-            _bucket_arg(self.bucket_size), int(k), grad_points.data_ptr(), ws.data_ptr(), ws.numel(),
-            _lib.stream_ptr()))
+        grad_points = _lib.glue().point_grad(grad_output, idx, alpha, self.bucket_size or 0, int(k))
         self.savedIndices = None                                                      # ref: :505
         return grad_output, grad_points

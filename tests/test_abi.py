@@ -66,3 +66,22 @@ def test_kernels_are_gfx950_only(lib):
     blob = open(_lib.LIB_PATH, 'rb').read()
     targets = set(re.findall(rb'hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-z]+)', blob))
     assert targets == {b'gfx950'}
+
+
+def test_native_glue_loads_and_fails_loudly_on_cpu_tensors():
+    """_qd_glue.so (csrc/qd_torch_glue.cpp) is the per-call binding the Python API uses: it must load, agree with
+    libqd_hip.so on the ABI version, and refuse CPU tensors -- there is no CPU path and no ctypes fallback for it."""
+    import pytest
+    import torch
+    from quantized_distillation_amd import _lib
+    g = _lib.glue()
+    assert g.abi_version() == _lib.load().qd_abi_version() == 1
+    for name in ('uniform', 'nearest', 'point_grad'):
+        assert callable(getattr(g, name))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        g.uniform(torch.zeros(8), 16, 256, False, 0.0, False, 0, False, False)
+    with pytest.raises(TypeError):
+        g.uniform([1.0, 2.0], 16, 256, False, 0.0, False, 0, False, False)
+    import quantization
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        quantization.uniformQuantization(torch.zeros(8), 16, bucket_size=4)

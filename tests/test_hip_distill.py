@@ -99,7 +99,7 @@ def test_backprop_styles_match_the_reference_loop(style, mode, first_last):
     the bucket-aware STE (K7) between the gradient exchange and optimizer.step()."""
     torch.backends.cudnn.deterministic = True
     t = make(mode, first_last=first_last, style=style)
-    t.flat_master.mul_(3.0)                              # push weights beyond [-1, 1] so that the clamp matters
+    t.flat_master.mul_(12.0)                             # push weights beyond [-1, 1] so that the clamp matters
     x, y = synthetic_batch(16, DEV, seed=5)
     want = _reference_style_step(t, x, y, style, first_last)
     before = t.flat_master.clone()
