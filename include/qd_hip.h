@@ -57,6 +57,14 @@ const char* qd_error_string(int code);
  * One buffer of this size per stream is enough; contents need no initialisation. */
 size_t qd_workspace_bytes(void);
 
+/* bucket_size=None tensors (one bucket = whole tensor) that fit the chip's register files are processed by ONE
+ * launch -- load once, grid-wide barrier on the per-block min/max, transform from registers (8 B/element) -- instead
+ * of reduce + fold + apply.  The barrier never blocks: under contention it gives up after 2 ms and one block finishes
+ * the tensor from memory.  mode 1 (default) = on, 0 = always the three-launch path, 2 = always give up at the barrier
+ * (exercises the contention path on an idle GPU; for tests).  Returns the previous mode; any other value restores
+ * the default (environment QD_SINGLE_FUSED=0|1|abandon).  Process-wide, not thread-safe against concurrent launches. */
+int qd_set_single_fused_mode(int mode);
+
 /* Number of buckets / padded length of the bucket view (help_functions.py:67-94). Host only. */
 int64_t qd_num_buckets(int64_t n, int64_t bucket);
 int64_t qd_padded_length(int64_t n, int64_t bucket);

@@ -45,6 +45,7 @@ SIGNATURES = {
     'qd_target_arch': (ctypes.c_char_p, []),
     'qd_error_string': (ctypes.c_char_p, [c_int]),
     'qd_workspace_bytes': (c_size, []),
+    'qd_set_single_fused_mode': (c_int, [c_int]),
     'qd_num_buckets': (i64, [i64, i64]),
     'qd_padded_length': (i64, [i64, i64]),
     'qd_mean_f32': (c_int, [c_f, i64, c_f, c_p, c_size, c_p]),

@@ -22,6 +22,7 @@
 #include "../../include/qd_hip.h"
 
 #include <math.h>
+#include <atomic>
 #include <stdlib.h>
 
 using namespace qd;
@@ -1038,6 +1039,242 @@ __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab
     }
 }
 
+// ---- single-bucket path in ONE launch for tensors that fit the register files ------------------
+// k_single_fused: every lane loads its share of the tensor ONCE into registers (V float4 per lane; 768 blocks
+// x 256 lanes x 24 float4 = 75 MB, the chip's VGPR files hold 128 MB), the blocks publish their min/max, meet at
+// a grid-wide barrier, and transform their registers with the folded (alpha, beta): the tensor is read from HBM
+// once and written once (8 B/element instead of 12) in one launch instead of three
+// (ref: quant_functions.py:85-87,95-97 with bucket_size=None).
+//
+// The barrier has NO counter.  Device-scope round trips cost 1-2 us on this chip (the coherence point is behind
+// the XCDs' private L2s) and same-address atomics serialise (~40 ns each): a counter that 780 blocks increment
+// and poll measured +35 us, a 32-way fan-out of it +22 us.  Instead every block writes its (min, max) into its
+// own slot, tagged with the launch's epoch (two 8-byte atomic stores, nothing to wait for), and then polls ALL G
+// slots -- each lane checks G/256 of them, one round trip per sweep -- until every slot carries this epoch; the
+// last sweep IS the fold.  No read-modify-write, no fence, no serialisation.
+//
+// The barrier is also OPTIMISTIC.  A grid barrier needs all blocks resident at the same time; the launch is
+// sized for that (<= occupancy x CUs), but another stream or process may hold part of the GPU, and two such
+// kernels could starve each other forever.  So a block that still misses a slot after 2 ms of the 100 MHz wall
+// clock gives up: it writes nothing and leaves (frees the CU).  Departures are counted (fan-out over 32 lines,
+// fire and forget); the LAST block to leave, seeing that somebody gave up, transforms the whole tensor alone
+// from memory -- every slot is published by then.  Blocks that did pass the barrier have written the same
+// values, so a mixed outcome is harmless; that needs out != x, so in-place calls take the three-launch path.
+// The control block lives in a __device__ array (zero-initialised when the module is loaded, per device and per
+// process; epoch 0 is never used), not in the caller's workspace, whose contents are undefined by contract;
+// the host hands every launch its own slot set (round robin over kFusedSlots, far more than the kernels a
+// process can have executing at once).
+constexpr int kFusedSlots = 64;
+constexpr int kFan = 32;
+constexpr long long kBarrierTimeout = 200000;          // 2 ms of the 100 MHz wall clock
+struct alignas(128) CtlLine { unsigned v; unsigned pad[31]; };
+struct FusedCtl {
+    unsigned long long slot[kPartialBlocks][2];   // {min bits | epoch << 32}, {max bits | epoch << 32}
+    CtlLine depart[kFan];
+    CtlLine top_depart;
+    CtlLine gave_up;
+};
+__device__ FusedCtl g_fused_ctl[kFusedSlots];
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// fan-out counter: true for exactly one caller, the one whose count completes its line and then the top word
+__device__ __forceinline__ bool fan_count(CtlLine* lines, CtlLine* top, unsigned block, unsigned G) {
+    const unsigned sub = block % kFan;
+    const unsigned expected = (G - sub + kFan - 1) / kFan;     // blocks with index % kFan == sub
+    const unsigned ntop = G < (unsigned)kFan ? G : (unsigned)kFan;
+    if (atomicAdd(&lines[sub].v, 1u) + 1u != expected) return false;
+    return atomicAdd(&top->v, 1u) + 1u == ntop;
+}
+
+template <int MODE>
+__device__ __forceinline__ f4 transform4(const KParams& p, const PointTable* T, f4 v, float a, float b, float mean,
+                                         int64_t i4, float (&side)[4]) {
+    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)i4, rnd);
+    f4 r;
+    r.x = transform<MODE>(p, T, v.x, a, b, mean, rnd[0], side[0]);
+    r.y = transform<MODE>(p, T, v.y, a, b, mean, rnd[1], side[1]);
+    r.z = transform<MODE>(p, T, v.z, a, b, mean, rnd[2], side[2]);
+    r.w = transform<MODE>(p, T, v.w, a, b, mean, rnd[3], side[3]);
+    return r;
+}
+
+// One sweep over the G slots (all threads of the block): true when every slot carries `epoch`; then (mn, mx) is the
+// fold of all partials (NaN in any of them poisons both, as torch's min/max do).
+__device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, unsigned epoch, float* red, float& mn, float& mx) {
+    float fmn = INFINITY, fmx = -INFINITY;
+    int fnan = 0, missing = 0;
+    for (unsigned i = threadIdx.x; i < G; i += blockDim.x) {
+        const unsigned long long a = ld_agent(&ctl->slot[i][0]);
+        const unsigned long long b = ld_agent(&ctl->slot[i][1]);
+        missing |= ((unsigned)(a >> 32) != epoch) | ((unsigned)(b >> 32) != epoch);
+        const float pm = __uint_as_float((unsigned)a), px = __uint_as_float((unsigned)b);
+        fnan |= (pm != pm);
+        fmn = fminf(fmn, pm);
+        fmx = fmaxf(fmx, px);
+    }
+    if (__syncthreads_or(missing)) return false;
+    block_minmax(fmn, fmx, red);
+    if (__syncthreads_or(fnan)) { fmn = NAN; fmx = NAN; }
+    mn = fmn; mx = fmx;
+    return true;
+}
+
+// V float4 per lane at W waves per SIMD: W = 4 gives 128 VGPRs (V <= 16), W = 3 gives 168 (V = 24: 768 resident blocks x
+// 256 lanes x 24 float4 = 75 MB, which covers WideResNet-16-22's largest tensor, 17.8 M elements = 71 MB).
+template <int MODE, int V, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
+void k_single_fused(KParams p, int slot_set, unsigned epoch, int force_give_up) {
+    __shared__ PointTable Ts;
+    __shared__ float red[32];
+    __shared__ int s_timed_out;
+    __shared__ int s_last;
+    const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+    const unsigned G = gridDim.x;
+    const unsigned ntop = G < (unsigned)kFan ? G : (unsigned)kFan;
+    FusedCtl* ctl = &g_fused_ctl[slot_set];
+    const int64_t n4 = p.n >> 2;
+    const f4* x4 = (const f4*)p.x;
+    f4* o4 = (f4*)p.out;
+
+    // ---- load once, reduce ----
+    f4 v[V];
+    float mn = INFINITY, mx = -INFINITY;
+    int nan = 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int64_t i = ((int64_t)j * G + blockIdx.x) * 256 + threadIdx.x;
+        if (i < n4) {
+            v[j] = prep4(ldg_nt(x4 + i), pp);
+            mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
+            mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+            nan |= has_nan4(v[j]);
+        }
+    }
+    float tail[3] = {0.f, 0.f, 0.f};
+    const int ntail = (int)(p.n & 3);
+    const bool owns_tail = blockIdx.x == 0 && threadIdx.x == 0;
+    if (owns_tail)
+        for (int t = 0; t < ntail; ++t) {
+            tail[t] = prep(p.x[(n4 << 2) + t], pp);
+            mn = fminf(mn, tail[t]); mx = fmaxf(mx, tail[t]);
+            nan |= (tail[t] != tail[t]);
+        }
+    block_minmax(mn, mx, red);
+    if (__syncthreads_or(nan)) { mn = NAN; mx = NAN; }      // NaN poisons the partial, hence the tensor
+
+    // ---- publish ----
+    if (threadIdx.x == 0) {
+        st_agent(&ctl->slot[blockIdx.x][0], (unsigned long long)__float_as_uint(mn) | ((unsigned long long)epoch << 32));
+        st_agent(&ctl->slot[blockIdx.x][1], (unsigned long long)__float_as_uint(mx) | ((unsigned long long)epoch << 32));
+        s_timed_out = force_give_up;
+    }
+    __syncthreads();
+
+    // ---- meet: sweep the slots until all carry this epoch (the successful sweep is the fold) ----
+    bool fast = false;
+    if (!force_give_up) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            if (sweep_slots(ctl, G, epoch, red, mn, mx)) { fast = true; break; }
+            if (threadIdx.x == 0 && wall_clock64() - t0 > kBarrierTimeout) s_timed_out = 1;
+            __syncthreads();
+            if (s_timed_out) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+
+    float a = 1.0f, b = 0.0f;
+    if (fast) {
+        alpha_beta(mn, mx, a, b);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (p.alpha) p.alpha[0] = a;
+            if (p.beta) p.beta[0] = b;
+        }
+        // ---- transform the registers ----
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int64_t i = ((int64_t)j * G + blockIdx.x) * 256 + threadIdx.x;
+            if (i < n4) {
+                float side[4];
+                const f4 r = transform4<MODE>(p, T, v[j], a, b, pp.mean, i, side);
+                stg_nt(r, o4 + i);
+                store_side4<MODE>(p, i << 2, side);
+            }
+        }
+        if (owns_tail)
+            for (int t = 0; t < ntail; ++t) {
+                const int64_t e = (n4 << 2) + t;
+                float rnd = 0.0f;
+                if (MODE == MODE_QDQ && p.stochastic) {
+                    float r4[4];
+                    philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
+                    rnd = r4[e & 3];
+                }
+                float side = 0.0f;
+                p.out[e] = transform<MODE>(p, T, tail[t], a, b, pp.mean, rnd, side);
+                store_side1<MODE>(p, e, side);
+            }
+    }
+
+    // ---- leave; the last block out cleans up after anybody who gave up ----
+    if (threadIdx.x == 0) {
+        if (!fast) atomicAdd(&ctl->gave_up.v, 1u);
+        s_last = fan_count(ctl->depart, &ctl->top_depart, blockIdx.x, G) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const bool redo = ld_agent(&ctl->gave_up.v) != 0u;     // every departure (and its gave_up increment) precedes this read
+    if (redo) {
+        // every block has published by now, so one sweep succeeds; then this block alone, from memory (x is intact)
+        while (!sweep_slots(ctl, G, epoch, red, mn, mx)) __builtin_amdgcn_s_sleep(4);
+        alpha_beta(mn, mx, a, b);
+        if (threadIdx.x == 0) {
+            if (p.alpha) p.alpha[0] = a;
+            if (p.beta) p.beta[0] = b;
+        }
+        for (int64_t i = threadIdx.x; i < n4; i += 256) {
+            float side[4];
+            const f4 r = transform4<MODE>(p, T, prep4(x4[i], pp), a, b, pp.mean, i, side);
+            o4[i] = r;
+            store_side4<MODE>(p, i << 2, side);
+        }
+        if (threadIdx.x == 0)
+            for (int t = 0; t < ntail; ++t) {
+                const int64_t e = (n4 << 2) + t;
+                float rnd = 0.0f;
+                if (MODE == MODE_QDQ && p.stochastic) {
+                    float r4[4];
+                    philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
+                    rnd = r4[e & 3];
+                }
+                float side = 0.0f;
+                p.out[e] = transform<MODE>(p, T, prep(p.x[e], pp), a, b, pp.mean, rnd, side);
+                store_side1<MODE>(p, e, side);
+            }
+    }
+    if (threadIdx.x == 0) {                                    // everybody has left: re-arm the counters
+        for (unsigned i = 0; i < ntop; ++i) st_agent(&ctl->depart[i].v, 0u);
+        st_agent(&ctl->gave_up.v, 0u);
+        __hip_atomic_store(&ctl->top_depart.v, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- mean (float64 accumulation, fixed order) -------------------------------------------------
 __global__ __launch_bounds__(256) void k_sum_partial(const float* x, int64_t n, double* part) {
     __shared__ double red[4];
@@ -1755,7 +1992,83 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     return check_launch();
 }
 
-// single bucket spanning a large tensor: reduce -> finalize -> apply
+// one-launch single bucket (k_single_fused) when the tensor fits the register files of a resident grid
+constexpr int kNotFused = -1000;
+// QD_SINGLE_FUSED=0: always the three-launch path (A/B measurements); =abandon: every barrier gives up at once, so the
+// contention fallback (SLOW path) runs on an idle GPU -- that is how the tests reach it deterministically.
+inline int fused_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("QD_SINGLE_FUSED");
+        mode = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1));
+    }
+    return mode;
+}
+int g_fused_override = -1;                                     // qd_set_single_fused_mode(); -1: follow the environment
+template <int MODE, int V, int W>
+int fused_capacity() {                                         // blocks of k_single_fused<MODE, V> resident at once, 0 if unusable
+    static int cap = -1;
+    if (cap < 0) {
+        int per_cu = 0;
+        hipFuncAttributes fa;
+        const void* fn = (const void*)k_single_fused<MODE, V, W>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess ||
+            hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.localSizeBytes != 0 /* spills: not worth it */)
+            per_cu = 0;
+        (void)hipGetLastError();
+        int c = per_cu * num_cus();
+        cap = c > kPartialBlocks ? kPartialBlocks : c;
+    }
+    return cap;
+}
+// one epoch sequence for ALL instantiations: a tag must never repeat on a slot set (epoch 0 = a never-written slot)
+std::atomic<unsigned> next_launch{1};
+template <int MODE>
+int launch_single_fused(KParams& p, hipStream_t st) {
+    const int fmode = g_fused_override >= 0 ? g_fused_override : fused_mode();
+    if (fmode == 0 || ((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) != 0) return kNotFused;
+    if ((const void*)p.x == (const void*)p.out) return kNotFused;   // in place: a give-up redo would read transformed data
+    // a captured launch would bake its barrier slot into the graph, and two replays in flight would share it
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap_status) != hipSuccess || cap_status != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return kNotFused;
+    }
+    if (MODE == MODE_NEAREST && p.idx && p.idx_bytes == 8 && (((uintptr_t)p.idx) & 15)) return kNotFused;
+    if (MODE == MODE_QDQ && p.lev8 && (((uintptr_t)p.lev8) & 3)) return kNotFused;
+    const int64_t n4 = p.n >> 2;
+    const int64_t lanes = (n4 + 255) / 256;                    // blocks needed at one float4 per lane
+    // Measured on MI355X (profiles/r02_k1g_fused.txt): a device-scope round trip costs 1.5-2 us, so the barrier adds ~3.5 us
+    // to a kernel -- about what a kernel boundary costs -- and the load and store phases of the register-resident kernel do
+    // not overlap, while the three-launch path's second read is served by the 256 MiB Infinity Cache.  One launch wins only
+    // where the call is launch-bound: up to 1 Mi elements (GPU time 7.8 vs 9.7 us at 0.1 M, 10.8 vs 10.9 at 0.8 M; one host
+    // launch instead of two); at 2.8 M / 5.3 M elements it measured 22 / 21 us against 16 / 17.5 us.
+    static int64_t max_n = 0;
+    if (max_n == 0) {
+        const char* e = getenv("QD_FUSED_MAX_N");              // tuning: largest tensor (elements) taken by the one-launch kernel
+        max_n = (e && atoll(e) > 0) ? atoll(e) : ((int64_t)1 << 20);
+    }
+    if (p.n > max_n) return kNotFused;
+#define QD_FUSED(V, W)                                                                                     \
+    {                                                                                                      \
+        const int cap = fused_capacity<MODE, V, W>();                                                      \
+        const int64_t blocks = (lanes + V - 1) / V;                                                        \
+        if (cap > 0 && blocks <= (cap < 256 ? cap : 256)) {   /* <= one block per CU: every block sweeps all G slots */ \
+            unsigned epoch = next_launch.fetch_add(1, std::memory_order_relaxed) & 0x7FFFFFFFu;            \
+            if (epoch == 0) epoch = next_launch.fetch_add(1, std::memory_order_relaxed) & 0x7FFFFFFFu;     \
+            const int slot = (int)(epoch % kFusedSlots);                                                   \
+            p.nvec = 0;                                                                                    \
+            hipLaunchKernelGGL((k_single_fused<MODE, V, W>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, p, \
+                               slot, epoch, fmode == 2 ? 1 : 0);                                           \
+            return check_launch();                                                                         \
+        }                                                                                                  \
+    }
+    QD_FUSED(1, 4) QD_FUSED(4, 4) QD_FUSED(16, 4)
+#undef QD_FUSED
+    return kNotFused;
+}
+
+// single bucket spanning a large tensor: one fused launch when it fits on chip, else reduce -> finalize -> apply
 template <int MODE>
 int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int64_t kSmall = 16384;
@@ -1766,6 +2079,10 @@ int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
     }
     Workspace w;
     if (!carve(ws, ws_bytes, w)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    if (!(MODE == MODE_NEAREST && p.prescaled)) {
+        const int rc = launch_single_fused<MODE>(p, st);
+        if (rc != kNotFused) return rc;
+    }
     const float* ab = nullptr;
     int nparts = 0;
     if (MODE == MODE_NEAREST && p.prescaled) {
@@ -1802,6 +2119,12 @@ int run_transform(KParams& p, int64_t bucket, void* ws, size_t ws_bytes, hipStre
 extern "C" {
 
 int qd_abi_version(void) { return 1; }
+
+int qd_set_single_fused_mode(int mode) {
+    const int prev = g_fused_override >= 0 ? g_fused_override : fused_mode();
+    g_fused_override = (mode >= 0 && mode <= 2) ? mode : -1;
+    return prev;
+}
 const char* qd_target_arch(void) { return "gfx950"; }
 
 const char* qd_error_string(int code) {

@@ -682,3 +682,101 @@ def test_nonuniform_single_bucket_of_exactly_bucket_size(n):
     fn = quantization.nonUniformQuantization_variable(bucket_size=n, pre_process_tensors=True, tensor=dev(x))
     q2 = fn.forward(None, torch.from_numpy(pts).to(DEV))
     assert np.array_equal(host(q2), onp.nonuniform_quantize(x, pts, n, 'midpoint')['q'])
+
+
+# ------------------------------------------------------------------------------ one-launch single bucket (k_single_fused)
+FUSED_SIZES = [16385, 65536 + 3, 262144, 1 << 20, 800000, 5308416 + 1, 1408 * 1408 * 9]
+
+
+@pytest.fixture
+def fused_mode():
+    lib = _lib.load()
+    prev = lib.qd_set_single_fused_mode(-1)
+
+    def set_mode(m):
+        lib.qd_set_single_fused_mode(m)
+    yield set_mode
+    lib.qd_set_single_fused_mode(-1)
+    assert prev in (0, 1, 2)
+
+
+@pytest.mark.parametrize('mode', [1, 2, 0], ids=['fused', 'fused-abandon-path', 'three-launch'])
+def test_single_bucket_paths_bit_exact(mode, fused_mode):
+    """bucket_size=None on every path the library can take for it -- the one-launch register-resident kernel, its
+    contention fallback (barrier gives up, one block finishes from memory) and the three-launch path -- against the
+    C oracle: q, alpha, beta bit-exact, for sizes that land on every V variant and with ragged tails."""
+    fused_mode(mode)
+    for n in FUSED_SIZES:
+        x = np.random.RandomState(n % 9973).randn(n).astype(np.float32) * 0.05
+        for s in (16, 4):
+            want = oc.uniform_quantize(x, s, None, want_idx=False, want_lev=False)
+            q, sf = quantization.uniformQuantization(dev(x), s)
+            assert np.array_equal(host(q), want['q']), (mode, n, s)
+            assert np.array_equal(host(sf.alpha).reshape(-1), want['alpha']) and np.array_equal(host(sf.beta).reshape(-1), want['beta'])
+        if n > 2_000_000 and mode == 2:
+            continue                                # the single-block fallback is slow by design: covered above
+        # clamp + mean, in place, sliced (unaligned base -> never fused), scale_down, non-uniform
+        want = oc.uniform_quantize(x, 16, None, max_element=0.08, subtract_mean=True, want_idx=False, want_lev=False)
+        q, sf = quantization.uniformQuantization(dev(x), 16, max_element=0.08, subtract_mean=True)
+        m = np.float32(host(sf.mean_tensor))
+        want_m = oc.uniform_quantize(x, 16, None, max_element=0.08, subtract_mean=True, mean=m, want_idx=False, want_lev=False)
+        assert abs(float(m) - float(want['mean'])) <= 2e-7 * max(1.0, abs(float(want['mean']))) + 1e-9
+        assert np.array_equal(host(q), want_m['q']), (mode, n, 'clamp+mean')
+        xd = dev(x)
+        q2, _ = quantization.uniformQuantization(xd, 16, modify_in_place=True)
+        assert q2.data_ptr() == xd.data_ptr() and np.array_equal(host(xd), oc.uniform_quantize(x, 16, None, want_idx=False, want_lev=False)['q'])
+        big = dev(np.concatenate([np.zeros(1, np.float32), x]))
+        q3, _ = quantization.uniformQuantization(big[1:], 16)
+        assert np.array_equal(host(q3), oc.uniform_quantize(x, 16, None, want_idx=False, want_lev=False)['q']), (mode, n, 'offset base')
+        sfs = quantization.ScalingFunction('linear', False, False, None)
+        u = sfs.scale_down(dev(x))
+        assert np.array_equal(host(u), oc.scale_down(x, None)['u']), (mode, n, 'scale_down')
+        pts = np.array([0.0, 0.3, 0.55, 1.0], np.float32)
+        qn, idx, _ = quantization.nonUniformQuantization(dev(x), torch.from_numpy(pts))
+        wn = oc.nonuniform_quantize(x, pts, None)
+        assert np.array_equal(host(qn), wn['q']) and np.array_equal(host(idx), wn['idx']), (mode, n, 'non-uniform')
+
+
+def test_single_bucket_fused_nan_stochastic_and_level_output(fused_mode):
+    import quantization.quant_functions as qf
+    from quantized_distillation_amd import codec
+    n = 300001
+    x = np.random.RandomState(3).randn(n).astype(np.float32)
+    outs = {}
+    for mode in (1, 2, 0):
+        fused_mode(mode)
+        qf._STOCHASTIC_CALLS[0] = 1234                     # same seed on every path
+        q, _ = quantization.uniformQuantization(dev(x), 16, stochastic_rounding=True)
+        outs[mode] = host(q)
+        h = codec.level_histogram(dev(x), 16, None)        # uint8 level side output of the same kernel
+        lev = oc.uniform_quantize(x, 16, None, want_idx=False)['lev']
+        assert np.array_equal(host(h), np.bincount(lev, minlength=16)), mode
+        xn = x.copy()
+        xn[n // 2] = np.nan
+        qn, sfn = quantization.uniformQuantization(dev(xn), 16)
+        assert np.isnan(host(qn)).all() and np.isnan(host(sfn.alpha)).all(), 'one NaN poisons the whole single bucket (as torch.min/max do)'
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[2], outs[0]), 'stochastic draws depend on (seed, element) only'
+
+
+def test_single_bucket_fused_under_contention_two_streams(fused_mode):
+    """Two streams launch register-resident kernels that cannot co-reside (71 MB each): whatever the barriers decide
+    -- meet, or give up and finish from memory -- nothing hangs and every result is bit-exact."""
+    fused_mode(1)
+    n = 1408 * 1408 * 9
+    xs = [np.random.RandomState(i).randn(n).astype(np.float32) for i in range(2)]
+    want = [oc.uniform_quantize(x, 16, None, want_idx=False, want_lev=False)['q'] for x in xs]
+    xd = [dev(x) for x in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    results = [[], []]
+    for rep in range(12):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                results[i].append(quantization.uniformQuantization(xd[i], 16)[0])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for q in results[i]:
+            assert np.array_equal(host(q), want[i])
+    # the barrier slots were re-armed: a later launch still works
+    q, _ = quantization.uniformQuantization(xd[0], 16)
+    assert np.array_equal(host(q), want[0])
