@@ -32,6 +32,16 @@ __device__ __forceinline__ int64_t uniform_wave_index() {
     return (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
+// ---- NaN-propagating min / max ----
+// torch's min/max propagate NaN (one NaN makes alpha, beta and every output of its bucket NaN in the reference), whereas
+// v_min_f32 / v_max_f32 (fminf / fmaxf) return the other operand.  gfx950 has the IEEE-754-2019 `minimum` / `maximum` as
+// three-operand instructions (v_minimum3_f32 / v_maximum3_f32): NaN if any operand is NaN, and two nested calls fuse into
+// one instruction.  Every min/max reduction of DATA below uses these, so no separate NaN flag has to be carried.
+__device__ __forceinline__ float pmin(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ float pmax(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ float pmin4(const f4& v) { return pmin(pmin(v.x, v.y), pmin(v.z, v.w)); }
+__device__ __forceinline__ float pmax4(const f4& v) { return pmax(pmax(v.x, v.y), pmax(v.z, v.w)); }
+
 // ---- DPP row rotations: lane i of each 16-lane row reads lane (i + s) mod 16 of its row ----
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -48,17 +58,17 @@ __device__ __forceinline__ int dpp_i(int v) {
 
 // all-reduce over the 16 lanes of a DPP row (min / max are idempotent; sum uses the same tree)
 __device__ __forceinline__ float row16_min(float v) {
-    v = fminf(v, dpp_f<QD_ROR8>(v));
-    v = fminf(v, dpp_f<QD_ROR4>(v));
-    v = fminf(v, dpp_f<QD_ROR2>(v));
-    v = fminf(v, dpp_f<QD_ROR1>(v));
+    v = pmin(v, dpp_f<QD_ROR8>(v));
+    v = pmin(v, dpp_f<QD_ROR4>(v));
+    v = pmin(v, dpp_f<QD_ROR2>(v));
+    v = pmin(v, dpp_f<QD_ROR1>(v));
     return v;
 }
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f<QD_ROR8>(v));
-    v = fmaxf(v, dpp_f<QD_ROR4>(v));
-    v = fmaxf(v, dpp_f<QD_ROR2>(v));
-    v = fmaxf(v, dpp_f<QD_ROR1>(v));
+    v = pmax(v, dpp_f<QD_ROR8>(v));
+    v = pmax(v, dpp_f<QD_ROR4>(v));
+    v = pmax(v, dpp_f<QD_ROR2>(v));
+    v = pmax(v, dpp_f<QD_ROR1>(v));
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
@@ -79,14 +89,14 @@ __device__ __forceinline__ int row16_imin(int v) {
 // all-reduce over the 64 lanes of a wave: row step by DPP, the two cross-row steps by bpermute
 __device__ __forceinline__ float wave_min(float v) {
     v = row16_min(v);
-    v = fminf(v, __shfl_xor(v, 16));
-    v = fminf(v, __shfl_xor(v, 32));
+    v = pmin(v, __shfl_xor(v, 16));
+    v = pmin(v, __shfl_xor(v, 32));
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = row16_max(v);
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
+    v = pmax(v, __shfl_xor(v, 16));
+    v = pmax(v, __shfl_xor(v, 32));
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -112,14 +122,14 @@ __device__ __forceinline__ long long wave_min_ll(long long v) {
 // all-reduce over a group of LANES lanes (16 = DPP row, 32 = half wave, 64 = wave)
 template <int LANES> __device__ __forceinline__ float group_min(float v) {
     v = row16_min(v);
-    if (LANES >= 32) v = fminf(v, __shfl_xor(v, 16));
-    if (LANES >= 64) v = fminf(v, __shfl_xor(v, 32));
+    if (LANES >= 32) v = pmin(v, __shfl_xor(v, 16));
+    if (LANES >= 64) v = pmin(v, __shfl_xor(v, 32));
     return v;
 }
 template <int LANES> __device__ __forceinline__ float group_max(float v) {
     v = row16_max(v);
-    if (LANES >= 32) v = fmaxf(v, __shfl_xor(v, 16));
-    if (LANES >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    if (LANES >= 32) v = pmax(v, __shfl_xor(v, 16));
+    if (LANES >= 64) v = pmax(v, __shfl_xor(v, 32));
     return v;
 }
 template <int LANES> __device__ __forceinline__ float group_sum(float v) {
@@ -147,7 +157,7 @@ __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* red) {
     if (lane == 0) { red[w] = mn; red[16 + w] = mx; }
     __syncthreads();
     float a = red[0], b = red[16];
-    for (int i = 1; i < nw; ++i) { a = fminf(a, red[i]); b = fmaxf(b, red[16 + i]); }
+    for (int i = 1; i < nw; ++i) { a = pmin(a, red[i]); b = pmax(b, red[16 + i]); }
     mn = a; mx = b;
 }
 
@@ -167,9 +177,10 @@ __device__ __forceinline__ f4 prep4(f4 v, const Prep& p) {
     return v;
 }
 
-// NaN poisoning: torch's min/max propagate NaN, so one NaN makes alpha, beta and every output of its
-// bucket NaN in the reference; v_min/v_max drop NaNs, so the flag is carried separately.  (Infinities
-// need nothing: alpha = inf or beta = -inf turn the bucket into NaN through the same arithmetic.)
+// NaN poisoning for the kernels that still reduce with a separate flag (the slow generic paths): torch's min/max
+// propagate NaN, so one NaN makes alpha, beta and every output of its bucket NaN in the reference.  The hot kernels use
+// pmin / pmax above instead.  (Infinities need nothing: alpha = inf or beta = -inf turn the bucket into NaN through the
+// same arithmetic.)
 __device__ __forceinline__ bool has_nan4(const f4& v) { return (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w); }
 // true for every lane of a LANES-wide group (16 = DPP row, 64 = wave) if any lane of it raised `flag`
 template <int LANES>
@@ -187,12 +198,36 @@ __device__ __forceinline__ void alpha_beta(float mn, float mx, float& a, float& 
     b = mn;
 }
 
+// ---- division by a bucket-invariant alpha ----
+// u = (x - beta) / alpha is the reference's IEEE division (quant_functions.py:106-107) and the level index
+// rint(u (s-1)) must match bit for bit, so no reciprocal shortcut -- but the divisor is the same for a whole bucket.
+// With y = RN(1 / alpha) computed ONCE per bucket by a true division (correctly rounded),
+//     q = RN(n y);  r = n - alpha q  (exact in one FMA);  u = RN(q + r y)
+// is the correctly rounded quotient RN(n / alpha) (Markstein 1990; the classic "division by a loop invariant"): three
+// VALU operations per element instead of the ~10 of the IEEE division macro.  Preconditions are no underflow in r and a
+// normal y; both hold for alpha in [2^-60, 2^100] and n = 0 or n >= 2^-100 (checked against true division on 5 * 10^9
+// adversarial pairs incl. all-ones significands: 0 mismatches; outside those ranges mismatches do occur).  A numerator
+// below 2^-100 with alpha >= 2^-60 gives u < 2^-40, whose level is 0 whatever its last bit is -- so the form is used
+// where only the LEVEL of u is consumed (quantize-dequantize, deterministic or stochastic), never where u itself is
+// returned (scale_down) or compared with points.  Buckets outside the range (incl. inf / NaN alpha) take the IEEE path.
+__device__ __forceinline__ bool fastdiv_ok(float a) { return a >= 0x1p-60f && a <= 0x1p100f; }   // false for NaN
+template <bool FAST>
+__device__ __forceinline__ float div_alpha(float n, float a, float y) {
+    if (FAST) {
+        const float q = n * y;
+        const float r = __builtin_fmaf(-a, q, n);
+        return __builtin_fmaf(r, y, q);
+    }
+    return n / a;
+}
+
 // ---- the k-level quantize-dequantize of one element (quant_functions.py:106-107,189-191,142-148)
 // Seven separately rounded fp32 ops; both divisions are IEEE-correct (no reciprocal shortcut):
 // the level index rint(u*(s-1)) must match the reference bit for bit.
-__device__ __forceinline__ float qdq(float v, float a, float b, float sm1, float mean, float& level) {
+template <bool FAST = false>
+__device__ __forceinline__ float qdq(float v, float a, float b, float sm1, float mean, float& level, float ry = 0.0f) {
     float u = v - b;
-    u = u / a;
+    u = div_alpha<FAST>(u, a, ry);
     float t = u * sm1;
     float r = rintf(t);
     level = r;
@@ -208,9 +243,11 @@ __device__ __forceinline__ float qdq(float v, float a, float b, float sm1, float
 // element fetches its level's entry with one ds_bpermute from its own row (rows are active or inactive as a whole
 // in the vector kernels).  Saves ~8 VALU instructions per element; bit-identical: level = rint(t) is an integer in
 // [0, sm1] for finite input, and for NaN (v_cvt_i32_f32 gives 0) w = 0 still yields NaN through a or b.
-__device__ __forceinline__ float qdq_tab(float v, float a, float b, float sm1, float mean, float& level, float tab) {
+template <bool FAST = false>
+__device__ __forceinline__ float qdq_tab(float v, float a, float b, float sm1, float mean, float& level, float tab,
+                                         float ry = 0.0f) {
     float u = v - b;
-    u = u / a;
+    u = div_alpha<FAST>(u, a, ry);
     float t = u * sm1;
     float r = rintf(t);
     level = r;
@@ -247,10 +284,11 @@ __device__ __forceinline__ void philox_uniform4(uint64_t seed, uint64_t block, f
     for (int i = 0; i < 4; ++i) out[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
 }
 // stochastic variant (quant_functions.py:174-187): floor + Bernoulli(frac)
+template <bool FAST = false>
 __device__ __forceinline__ float qdq_stochastic(float v, float a, float b, float sm1, float mean, float rnd,
-                                                float& level) {
+                                                float& level, float ry = 0.0f) {
     float u = v - b;
-    u = u / a;
+    u = div_alpha<FAST>(u, a, ry);
     float t = u * sm1;     // == probabilities before the subtraction (same product)
     float l = floorf(t);
     float p = t - l;
@@ -265,10 +303,11 @@ __device__ __forceinline__ float qdq_stochastic(float v, float a, float b, float
 }
 
 // stochastic variant with the same per-row table for floor(t) / sm1 (levels <= 16)
+template <bool FAST = false>
 __device__ __forceinline__ float qdq_stochastic_tab(float v, float a, float b, float sm1, float mean, float rnd,
-                                                    float& level, float tab) {
+                                                    float& level, float tab, float ry = 0.0f) {
     float u = v - b;
-    u = u / a;
+    u = div_alpha<FAST>(u, a, ry);
     float t = u * sm1;
     float l = floorf(t);
     float p = t - l;

@@ -23,6 +23,7 @@
 
 #include <math.h>
 #include <atomic>
+#include <type_traits>
 #include <stdlib.h>
 
 using namespace qd;
@@ -139,11 +140,12 @@ __device__ __forceinline__ int assign_point(const PointTable& T, int k, int mode
 // ---- per-element transform shared by every bucket kernel -----------------------------------
 // v: prepared value (mean subtracted, clamped) -- or u itself when prescaled.
 // e: global element index (for the side outputs and the random stream).
-template <int MODE>
+template <int MODE, bool FAST = false>
 __device__ __forceinline__ float transform(const KParams& p, const PointTable* T, float v, float a, float b,
-                                           float mean, float rnd, float& side) {
+                                           float mean, float rnd, float& side, float y = 0.0f) {
     if (MODE == MODE_QDQ) {
-        return p.stochastic ? qdq_stochastic(v, a, b, p.sm1, mean, rnd, side) : qdq(v, a, b, p.sm1, mean, side);
+        return p.stochastic ? qdq_stochastic<FAST>(v, a, b, p.sm1, mean, rnd, side, y)
+                            : qdq<FAST>(v, a, b, p.sm1, mean, side, y);
     } else if (MODE == MODE_SCALE) {
         float u = v - b;
         u = u / a;
@@ -338,6 +340,101 @@ __device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable*
 // LPB == 16: a DPP row owns a bucket; LPB == 64: the whole wave owns a bucket (large buckets).
 // U = consecutive buckets each lane group handles per tile, so that a wave always streams 4 KiB
 // per tile (U*V == 4 float4 per lane in flight) whatever the bucket size.
+
+// wave-uniform facts about the call that the per-bucket code branches on
+struct VecFlags {
+    bool prescaled;   // NEAREST with u, alpha, beta given
+    bool prep_on;     // mean subtraction / clamp requested
+    bool use_tab;     // QDQ, deterministic, <= 16 levels: level / (s-1) from the per-row table
+    bool use_tab_s;   // same for the stochastic branch
+    float tab;        // this lane's table entry: (lane & 15) / (s-1)
+};
+
+// The transform + store half of vec_bucket for one code variant: VAR 0 = deterministic with the per-row level table
+// (<= 16 levels), 1 = stochastic with the table, 2 = generic transform<MODE>; FAST = bucket-invariant division.
+template <int MODE, int LPB, int V, int VAR, bool FAST>
+__device__ __forceinline__ void vec_apply(const KParams& p, const PointTable* T, const Prep& pp, const VecFlags& fl,
+                                          f4 (&v)[V], int64_t e0, float a, float b) {
+    // The seed goes through an opaque (empty) asm per instantiation: without it LLVM hoists the code the variants share --
+    // the whole Philox draw of the stochastic and generic variants -- in front of the variant dispatch, where the
+    // deterministic path executes it too (that is what round 1's kernel did: 12 of its 32 VALU instructions per element
+    // were an unused random draw).
+    uint32_t seed_lo = (uint32_t)p.seed, seed_hi = (uint32_t)(p.seed >> 32);
+    if (MODE == MODE_QDQ && VAR != 0) asm volatile("; seed of variant %2" : "+s"(seed_lo), "+s"(seed_hi) : "n"(VAR * 2 + (FAST ? 1 : 0)));
+    const uint64_t seed = (uint64_t)seed_lo | ((uint64_t)seed_hi << 32);
+    uint32_t ctr_lo = (uint32_t)e0, ctr_hi = (uint32_t)((uint64_t)e0 >> 32);         // same for the counter (round 1 is seed-free)
+    if (MODE == MODE_QDQ && VAR != 0) asm volatile("; counter of variant %2" : "+v"(ctr_lo), "+v"(ctr_hi) : "n"(VAR * 2 + (FAST ? 1 : 0)));
+    const uint64_t ctr0 = (uint64_t)ctr_lo | ((uint64_t)ctr_hi << 32);
+    f4* dst = (f4*)(p.out + e0);
+    const float y = FAST ? 1.0f / a : 0.0f;             // RN(1/alpha): one IEEE division per bucket and lane
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int64_t e = e0 + (int64_t)j * LPB * 4;
+        float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == MODE_QDQ && VAR != 0 && p.stochastic) philox_uniform4(seed, (ctr0 + (uint64_t)j * LPB * 4) >> 2, rnd);
+        float side[4];
+        f4 r;
+        if (MODE == MODE_QDQ && VAR == 0) {
+            r.x = qdq_tab<FAST>(v[j].x, a, b, p.sm1, pp.mean, side[0], fl.tab, y);
+            r.y = qdq_tab<FAST>(v[j].y, a, b, p.sm1, pp.mean, side[1], fl.tab, y);
+            r.z = qdq_tab<FAST>(v[j].z, a, b, p.sm1, pp.mean, side[2], fl.tab, y);
+            r.w = qdq_tab<FAST>(v[j].w, a, b, p.sm1, pp.mean, side[3], fl.tab, y);
+        } else if (MODE == MODE_QDQ && VAR == 1) {
+            r.x = qdq_stochastic_tab<FAST>(v[j].x, a, b, p.sm1, pp.mean, rnd[0], side[0], fl.tab, y);
+            r.y = qdq_stochastic_tab<FAST>(v[j].y, a, b, p.sm1, pp.mean, rnd[1], side[1], fl.tab, y);
+            r.z = qdq_stochastic_tab<FAST>(v[j].z, a, b, p.sm1, pp.mean, rnd[2], side[2], fl.tab, y);
+            r.w = qdq_stochastic_tab<FAST>(v[j].w, a, b, p.sm1, pp.mean, rnd[3], side[3], fl.tab, y);
+        } else {
+            r.x = transform<MODE, FAST>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0], y);
+            r.y = transform<MODE, FAST>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1], y);
+            r.z = transform<MODE, FAST>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2], y);
+            r.w = transform<MODE, FAST>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3], y);
+        }
+        __builtin_nontemporal_store(r, dst + j * LPB);
+        store_side4_row<MODE>(p, e, side);
+    }
+}
+
+// One bucket held in registers by its LPB lanes (v[0..V): this lane's float4s, already loaded): reduce, transform,
+// store.  The ONLY copy of the per-bucket arithmetic of the vector kernels: both loop shapes of k_bucket_vec call it.
+template <int MODE, int LPB, int V>
+__device__ __forceinline__ void vec_bucket(const KParams& p, const PointTable* T, const Prep& pp, const VecFlags& fl,
+                                           f4 (&v)[V], int64_t bkt, int uu, int l, float& a_keep, float& b_keep) {
+    constexpr int ROW = LPB * V * 4;
+    const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
+    float a, b;
+    if (fl.prescaled) {
+        a = p.alpha[bkt]; b = p.beta[bkt];
+    } else {
+        if (MODE != MODE_QDQ || fl.prep_on) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
+        }
+        float mn = pmin4(v[0]), mx = pmax4(v[0]);           // NaN-propagating: a NaN element makes both NaN
+#pragma unroll
+        for (int j = 1; j < V; ++j) { mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j])); }
+        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
+        else { mn = wave_min(mn); mx = wave_max(mx); }
+        alpha_beta(mn, mx, a, b);
+        if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
+    }
+    // quantize-dequantize consumes only the LEVEL of u, so the bucket-invariant division form is exact there (qd_common.h);
+    // wave-uniform choice: every bucket of the wave must be in the proven range.  The transform loop is instantiated per
+    // (variant, division form) and chosen ONCE per bucket: with the flags tested inside the loop the compiler no longer
+    // unswitched it and the kernel executed 37.9 M instead of 33.9 M VALU wave-instructions (profiles/r02_sq_counters.txt).
+    const bool fast = MODE == MODE_QDQ && !__any(!fastdiv_ok(a));
+    if (MODE != MODE_QDQ) vec_apply<MODE, LPB, V, 2, false>(p, T, pp, fl, v, e0, a, b);
+    else if (fast) {
+        if (fl.use_tab) vec_apply<MODE, LPB, V, 0, true>(p, T, pp, fl, v, e0, a, b);
+        else if (fl.use_tab_s) vec_apply<MODE, LPB, V, 1, true>(p, T, pp, fl, v, e0, a, b);
+        else vec_apply<MODE, LPB, V, 2, true>(p, T, pp, fl, v, e0, a, b);
+    } else {
+        if (fl.use_tab) vec_apply<MODE, LPB, V, 0, false>(p, T, pp, fl, v, e0, a, b);
+        else if (fl.use_tab_s) vec_apply<MODE, LPB, V, 1, false>(p, T, pp, fl, v, e0, a, b);
+        else vec_apply<MODE, LPB, V, 2, false>(p, T, pp, fl, v, e0, a, b);
+    }
+}
+
 template <int MODE, int LPB, int V, int U>
 __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     __shared__ PointTable Ts;
@@ -352,194 +449,56 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
-    const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
     // wave-uniform shortcuts of the common configuration (no mean, no clamp, <= 16 levels, deterministic): they
     // take the kernel from ~43 to ~30 VALU instructions per element, which keeps it HBM-bound on boxes whose
     // sustained clock is lower (measured: 88 us vs 85.8 us for the leaner kbench kernel on the same box)
     // (MODE_QDQ only, so that the code generated for the other modes is untouched: the point-search kernels are
     // sensitive to it -- K5 at k = 256 went from 112 to 124 us when these branches were compiled into them.)
-    const bool prep_on = MODE != MODE_QDQ || p.mean != nullptr || p.me != INFINITY;
-    const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
-    const bool use_tab_s = MODE == MODE_QDQ && p.stochastic && p.sm1 <= 15.0f;
-    const float tab = MODE == MODE_QDQ ? (float)(lane & 15) / p.sm1 : 0.0f;
+    VecFlags fl;
+    fl.prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    fl.prep_on = MODE != MODE_QDQ || p.mean != nullptr || p.me != INFINITY;
+    fl.use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
+    fl.use_tab_s = MODE == MODE_QDQ && p.stochastic && p.sm1 <= 15.0f;
+    fl.tab = MODE == MODE_QDQ ? (float)(lane & 15) / p.sm1 : 0.0f;
 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t ntiles = (p.nvec + BPW - 1) / BPW;
 
-    // Two code shapes, chosen at compile time by what the compiler turns into the fewest VALU
-    // instructions (SQ_INSTS_VALU, profiles/r01_sq_counters.txt): with one bucket per lane group the
-    // straight-line loop is best (bucket 256: 44.9 M vs 60.3 M wave-instructions); with several
-    // buckets per group the unpredicated whole-tile path is (bucket 64: 52.9 M vs 74.6 M).
-    if constexpr (U == 1) {
-        for (int64_t t = wave; t < ntiles; t += nwaves) {
-            const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
+    // One loop shape around the one vec_bucket(): whole tiles unpredicated (all loads, then the buckets), the last,
+    // partial tile bucket by bucket.
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+        const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
+        float a_keep = 0.0f, b_keep = 0.0f;
+        if (bkt0 + U <= p.nvec) {
+            // whole group in range (every tile but possibly the last): unpredicated.  All loads first, then the buckets
+            // one after the other.
             f4 v[U][V];
-            float a_keep = 0.0f, b_keep = 0.0f;
 #pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
+            }
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) vec_bucket<MODE, LPB, V>(p, T, pp, fl, v[uu], bkt0 + uu, uu, l, a_keep, b_keep);
+        } else {
             for (int uu = 0; uu < U; ++uu) {
                 if (bkt0 + uu < p.nvec) {
+                    f4 v[V];
                     const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
 #pragma unroll
-                    for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
+                    for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * LPB);
+                    vec_bucket<MODE, LPB, V>(p, T, pp, fl, v, bkt0 + uu, uu, l, a_keep, b_keep);
                 }
-            }
-#pragma unroll
-            for (int uu = 0; uu < U; ++uu) {
-                const int64_t bkt = bkt0 + uu;
-                if (bkt < p.nvec) {
-                    const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
-                    float a, b;
-                    if (prescaled) {
-                        a = p.alpha[bkt]; b = p.beta[bkt];
-                    } else {
-                        if (MODE != MODE_QDQ || prep_on) {
-#pragma unroll
-                            for (int j = 0; j < V; ++j) v[uu][j] = prep4(v[uu][j], pp);
-                        }
-                        float mn = fminf(fminf(v[uu][0].x, v[uu][0].y), fminf(v[uu][0].z, v[uu][0].w));
-                        float mx = fmaxf(fmaxf(v[uu][0].x, v[uu][0].y), fmaxf(v[uu][0].z, v[uu][0].w));
-#pragma unroll
-                        for (int j = 1; j < V; ++j) {
-                            mn = fminf(mn, fminf(fminf(v[uu][j].x, v[uu][j].y), fminf(v[uu][j].z, v[uu][j].w)));
-                            mx = fmaxf(mx, fmaxf(fmaxf(v[uu][j].x, v[uu][j].y), fmaxf(v[uu][j].z, v[uu][j].w)));
-                        }
-                        bool nan = false;
-#pragma unroll
-                        for (int j = 0; j < V; ++j) nan |= has_nan4(v[uu][j]);
-                        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
-                        else { mn = wave_min(mn); mx = wave_max(mx); }
-                        if (group_any<LPB>(nan)) { mn = NAN; mx = NAN; }
-                        alpha_beta(mn, mx, a, b);
-                        if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
-                    }
-                    f4* dst = (f4*)(p.out + e0);
-#pragma unroll
-                    for (int j = 0; j < V; ++j) {
-                        const int64_t e = e0 + (int64_t)j * LPB * 4;
-                        float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
-                        float side[4];
-                        f4 r;
-                        if (MODE == MODE_QDQ && use_tab) {
-                            r.x = qdq_tab(v[uu][j].x, a, b, p.sm1, pp.mean, side[0], tab);
-                            r.y = qdq_tab(v[uu][j].y, a, b, p.sm1, pp.mean, side[1], tab);
-                            r.z = qdq_tab(v[uu][j].z, a, b, p.sm1, pp.mean, side[2], tab);
-                            r.w = qdq_tab(v[uu][j].w, a, b, p.sm1, pp.mean, side[3], tab);
-                        } else if (MODE == MODE_QDQ && use_tab_s) {
-                            r.x = qdq_stochastic_tab(v[uu][j].x, a, b, p.sm1, pp.mean, rnd[0], side[0], tab);
-                            r.y = qdq_stochastic_tab(v[uu][j].y, a, b, p.sm1, pp.mean, rnd[1], side[1], tab);
-                            r.z = qdq_stochastic_tab(v[uu][j].z, a, b, p.sm1, pp.mean, rnd[2], side[2], tab);
-                            r.w = qdq_stochastic_tab(v[uu][j].w, a, b, p.sm1, pp.mean, rnd[3], side[3], tab);
-                        } else {
-                            r.x = transform<MODE>(p, T, v[uu][j].x, a, b, pp.mean, rnd[0], side[0]);
-                            r.y = transform<MODE>(p, T, v[uu][j].y, a, b, pp.mean, rnd[1], side[1]);
-                            r.z = transform<MODE>(p, T, v[uu][j].z, a, b, pp.mean, rnd[2], side[2]);
-                            r.w = transform<MODE>(p, T, v[uu][j].w, a, b, pp.mean, rnd[3], side[3]);
-                        }
-                        __builtin_nontemporal_store(r, dst + j * LPB);
-                        store_side4_row<MODE>(p, e, side);
-                    }
-                }
-            }
-            // alpha/beta of the group's U buckets: lanes 0..U-1 write U consecutive floats (one store
-            // instruction per array per tile instead of U single-lane stores)
-            if (!prescaled && l < U && bkt0 + l < p.nvec) {
-                if (p.alpha) p.alpha[bkt0 + l] = a_keep;
-                if (p.beta) p.beta[bkt0 + l] = b_keep;
             }
         }
-
-    } else {
-        // one bucket: v[0..V) are already loaded; reduce, transform, store
-        auto process = [&](f4 (&v)[V], int64_t bkt, int uu, float& a_keep, float& b_keep) {
-            const int64_t e0 = bkt * ROW + (int64_t)l * 4;     // first element of this lane
-            float a, b;
-            if (prescaled) {
-                a = p.alpha[bkt]; b = p.beta[bkt];
-            } else {
-                if (MODE != MODE_QDQ || prep_on) {
-#pragma unroll
-                    for (int j = 0; j < V; ++j) v[j] = prep4(v[j], pp);
-                }
-                float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
-                float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
-#pragma unroll
-                for (int j = 1; j < V; ++j) {
-                    mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
-                    mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
-                }
-                bool nan = false;
-#pragma unroll
-                for (int j = 0; j < V; ++j) nan |= has_nan4(v[j]);
-                if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); }
-                else { mn = wave_min(mn); mx = wave_max(mx); }
-                if (group_any<LPB>(nan)) { mn = NAN; mx = NAN; }
-                alpha_beta(mn, mx, a, b);
-                if (l == uu) { a_keep = a; b_keep = b; }       // lane uu of the group keeps bucket uu's pair
-            }
-            f4* dst = (f4*)(p.out + e0);
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const int64_t e = e0 + (int64_t)j * LPB * 4;
-                float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
-                float side[4];
-                f4 r;
-                if (MODE == MODE_QDQ && use_tab) {
-                    r.x = qdq_tab(v[j].x, a, b, p.sm1, pp.mean, side[0], tab);
-                    r.y = qdq_tab(v[j].y, a, b, p.sm1, pp.mean, side[1], tab);
-                    r.z = qdq_tab(v[j].z, a, b, p.sm1, pp.mean, side[2], tab);
-                    r.w = qdq_tab(v[j].w, a, b, p.sm1, pp.mean, side[3], tab);
-                } else if (MODE == MODE_QDQ && use_tab_s) {
-                    r.x = qdq_stochastic_tab(v[j].x, a, b, p.sm1, pp.mean, rnd[0], side[0], tab);
-                    r.y = qdq_stochastic_tab(v[j].y, a, b, p.sm1, pp.mean, rnd[1], side[1], tab);
-                    r.z = qdq_stochastic_tab(v[j].z, a, b, p.sm1, pp.mean, rnd[2], side[2], tab);
-                    r.w = qdq_stochastic_tab(v[j].w, a, b, p.sm1, pp.mean, rnd[3], side[3], tab);
-                } else {
-                    r.x = transform<MODE>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0]);
-                    r.y = transform<MODE>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1]);
-                    r.z = transform<MODE>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2]);
-                    r.w = transform<MODE>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3]);
-                }
-                __builtin_nontemporal_store(r, dst + j * LPB);
-                store_side4_row<MODE>(p, e, side);
-            }
-        };
-
-        for (int64_t t = wave; t < ntiles; t += nwaves) {
-            const int64_t bkt0 = t * BPW + (int64_t)sub * U;          // first of this group's U buckets
-            float a_keep = 0.0f, b_keep = 0.0f;
-            if (bkt0 + U <= p.nvec) {
-                // whole group in range (every tile but possibly the last): unpredicated, all loads first
-                f4 v[U][V];
-#pragma unroll
-                for (int uu = 0; uu < U; ++uu) {
-                    const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
-#pragma unroll
-                    for (int j = 0; j < V; ++j) v[uu][j] = __builtin_nontemporal_load(src + j * LPB);
-                }
-#pragma unroll
-                for (int uu = 0; uu < U; ++uu) process(v[uu], bkt0 + uu, uu, a_keep, b_keep);
-            } else {
-                for (int uu = 0; uu < U; ++uu) {
-                    if (bkt0 + uu < p.nvec) {
-                        f4 v[V];
-                        const f4* src = (const f4*)(p.x + (bkt0 + uu) * ROW + (int64_t)l * 4);
-#pragma unroll
-                        for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load(src + j * LPB);
-                        process(v, bkt0 + uu, uu, a_keep, b_keep);
-                    }
-                }
-            }
-            // alpha/beta of the group's U buckets: lanes 0..U-1 write U consecutive floats (one store
-            // instruction per array per tile instead of U single-lane stores)
-            if (!prescaled && l < U && bkt0 + l < p.nvec) {
-                if (p.alpha) p.alpha[bkt0 + l] = a_keep;
-                if (p.beta) p.beta[bkt0 + l] = b_keep;
-            }
+        // alpha/beta of the group's U buckets: lanes 0..U-1 write U consecutive floats (one store
+        // instruction per array per tile instead of U single-lane stores)
+        if (!fl.prescaled && l < U && bkt0 + l < p.nvec) {
+            if (p.alpha) p.alpha[bkt0 + l] = a_keep;
+            if (p.beta) p.beta[bkt0 + l] = b_keep;
         }
-
     }
 
     // buckets after the vector part (the ragged last bucket): one DPP row each, last block
@@ -566,10 +525,11 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
     __shared__ PointTable Ts;
     const PointTable* T = nullptr;
     if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
-    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: pairs[VMAX * 64], ab[256]
+    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: pairs[VMAX * 64], ab[256], 1/alpha[256]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float2* pr = chunk_lds + w * (VMAX * 64 + 256);
+    float2* pr = chunk_lds + w * (VMAX * 64 + 256 + 128);
     float2* ab = pr + VMAX * 64;
+    float* yt = (float*)(ab + 256);
 
     const int Bq = (int)(p.row >> 2);                  // float4 per bucket
     const int nf = m * Bq;                             // float4 per chunk
@@ -603,40 +563,36 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
             v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
         }
         __builtin_amdgcn_sched_barrier(0);             // all loads in flight before the first use
+        bool div_ok = true;
         if (!prescaled) {
 #pragma unroll
             for (int j = 0; j < VMAX; ++j) {
                 const int f = lane + 64 * j;
                 if (j < nj && f < nf) {
                     if (prep_on) v[j] = prep4(v[j], pp);
-                    float mn = fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w));
-                    const float mx = fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w));
-                    if (has_nan4(v[j])) mn = NAN;      // carried as a NaN minimum (v_min would drop it)
-                    pr[f] = make_float2(mn, mx);
+                    pr[f] = make_float2(pmin4(v[j]), pmax4(v[j]));     // NaN-propagating
                 }
             }
             // LDS operations of one wave complete in order; the fence/barrier only stop compiler reordering
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int bb = bl; bb < m; bb += mlanes) {  // uniform trip count: m is a multiple of mlanes
+            for (int bb = bl; bb < m; bb += mlanes) {  // G > 1: m is a multiple of mlanes, so the trip count is uniform
                 const float2* q = pr + bb * Bq;
                 float mn = INFINITY, mx = -INFINITY;
-                int nan = 0;
                 for (int t = sub; t < Bq; t += G) {
                     const float2 pm = q[t];
-                    nan |= (pm.x != pm.x);
-                    mn = fminf(mn, pm.x); mx = fmaxf(mx, pm.y);
+                    mn = pmin(mn, pm.x); mx = pmax(mx, pm.y);
                 }
                 for (int sft = 1; sft < G; sft <<= 1) {
-                    mn = fminf(mn, __shfl_xor(mn, sft));
-                    mx = fmaxf(mx, __shfl_xor(mx, sft));
-                    nan |= __shfl_xor(nan, sft);
+                    mn = pmin(mn, __shfl_xor(mn, sft));
+                    mx = pmax(mx, __shfl_xor(mx, sft));
                 }
-                if (nan) { mn = NAN; mx = NAN; }
                 float a, b;
                 alpha_beta(mn, mx, a, b);
+                div_ok &= fastdiv_ok(a);
                 if (sub == 0) {
                     ab[bb] = make_float2(a, b);
+                    yt[bb] = 1.0f / a;                  // RN(1/alpha), one IEEE division per bucket
                     if (p.alpha) p.alpha[b0 + bb] = a;
                     if (p.beta) p.beta[b0 + bb] = b;
                 }
@@ -647,36 +603,45 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f4* dst = (f4*)(p.out + e0);
-        int q = q0, r = r0;
+        // only the level of u is consumed by quantize-dequantize: bucket-invariant division (qd_common.h) when every
+        // bucket of the chunk is in its proven range
+        const bool fast = MODE == MODE_QDQ && !prescaled && !__any(!div_ok);
+        auto body = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            int q = q0, r = r0;
 #pragma unroll
-        for (int j = 0; j < VMAX; ++j) {
-            const int f = lane + 64 * j;
-            if (j < nj) {                                  // whole wave: lanes past the chunk work on their duplicate
-                const float2 s = ab[q < m ? q : m - 1];
-                const int64_t e = e0 + ((int64_t)f << 2);
-                float side[4];
-                f4 o;
-                if (use_tab) {                             // <= 16 levels, deterministic: see k_bucket_vec
-                    o.x = qdq_tab(v[j].x, s.x, s.y, p.sm1, pp.mean, side[0], tab);
-                    o.y = qdq_tab(v[j].y, s.x, s.y, p.sm1, pp.mean, side[1], tab);
-                    o.z = qdq_tab(v[j].z, s.x, s.y, p.sm1, pp.mean, side[2], tab);
-                    o.w = qdq_tab(v[j].w, s.x, s.y, p.sm1, pp.mean, side[3], tab);
-                } else {
-                    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
-                    o.x = transform<MODE>(p, T, v[j].x, s.x, s.y, pp.mean, rnd[0], side[0]);
-                    o.y = transform<MODE>(p, T, v[j].y, s.x, s.y, pp.mean, rnd[1], side[1]);
-                    o.z = transform<MODE>(p, T, v[j].z, s.x, s.y, pp.mean, rnd[2], side[2]);
-                    o.w = transform<MODE>(p, T, v[j].w, s.x, s.y, pp.mean, rnd[3], side[3]);
+            for (int j = 0; j < VMAX; ++j) {
+                const int f = lane + 64 * j;
+                if (j < nj) {                                  // whole wave: lanes past the chunk work on their duplicate
+                    const int qi = q < m ? q : m - 1;
+                    const float2 s = ab[qi];
+                    const float y = FAST ? yt[qi] : 0.0f;
+                    const int64_t e = e0 + ((int64_t)f << 2);
+                    float side[4];
+                    f4 o;
+                    if (use_tab) {                             // <= 16 levels, deterministic: see k_bucket_vec
+                        o.x = qdq_tab<FAST>(v[j].x, s.x, s.y, p.sm1, pp.mean, side[0], tab, y);
+                        o.y = qdq_tab<FAST>(v[j].y, s.x, s.y, p.sm1, pp.mean, side[1], tab, y);
+                        o.z = qdq_tab<FAST>(v[j].z, s.x, s.y, p.sm1, pp.mean, side[2], tab, y);
+                        o.w = qdq_tab<FAST>(v[j].w, s.x, s.y, p.sm1, pp.mean, side[3], tab, y);
+                    } else {
+                        float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                        o.x = transform<MODE, FAST>(p, T, v[j].x, s.x, s.y, pp.mean, rnd[0], side[0], y);
+                        o.y = transform<MODE, FAST>(p, T, v[j].y, s.x, s.y, pp.mean, rnd[1], side[1], y);
+                        o.z = transform<MODE, FAST>(p, T, v[j].z, s.x, s.y, pp.mean, rnd[2], side[2], y);
+                        o.w = transform<MODE, FAST>(p, T, v[j].w, s.x, s.y, pp.mean, rnd[3], side[3], y);
+                    }
+                    if (f < nf) {
+                        __builtin_nontemporal_store(o, dst + f);
+                        store_side4<MODE>(p, e, side);
+                    }
                 }
-                if (f < nf) {
-                    __builtin_nontemporal_store(o, dst + f);
-                    store_side4<MODE>(p, e, side);
-                }
+                q += step_q; r += step_r;
+                if (r >= Bq) { r -= Bq; ++q; }
             }
-            q += step_q; r += step_r;
-            if (r >= Bq) { r -= Bq; ++q; }
-        }
+        };
+        if (fast) body(std::true_type{}); else body(std::false_type{});
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next chunk overwrites pr / ab
         __builtin_amdgcn_wave_barrier();
     }
@@ -693,28 +658,31 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
 }
 
 // Same for bucket sizes that are NOT a multiple of 4 (33, 50, 7, ... >= 4): m is a multiple of 4, so every chunk
-// still starts 16-byte aligned and holds a whole number of float4, but a float4 may straddle two buckets (never
-// three: row >= 4).  The prepared values themselves go through LDS (16 B per float4), the reduce step reads its
-// bucket element by element, and the transform picks (alpha, beta) per element from the two candidate buckets.
+// still starts 16-byte aligned and holds a whole number of float4, but a float4 may straddle two buckets.  So the
+// registers only carry the chunk between HBM and LDS: the prepared values are staged in LDS (16 B per float4), the lane
+// (group) that reduces a bucket goes straight on to TRANSFORM it in place in LDS -- alpha, beta and 1/alpha are then
+// per-lane constants, no per-element choice between two buckets, and no register array stays live across the phases --
+// and finally every lane streams its float4s from LDS to HBM, coalesced.  (The first version transformed the register
+// copy and picked (alpha, beta) per element from the two candidate buckets: 48 VALU instructions per element against
+// 32 in the vector kernel, VALU-bound at 107-138 us for 64 Mi elements.)
 template <int MODE, int VMAX>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4)))
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 6)))
 void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
     __shared__ PointTable Ts;
     const PointTable* T = nullptr;
     if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
-    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: vals[VMAX * 256] floats, ab[256]
+    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: vals[VMAX * 256] floats
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float* vals = (float*)(chunk_lds + w * (VMAX * 128 + 256));
-    float2* ab = (float2*)(vals + VMAX * 256);
+    float* vals = (float*)(chunk_lds + w * (VMAX * 128));
 
     const int B = (int)p.row;
     const int nf = (m * B) >> 2;                       // float4 per chunk (m % 4 == 0)
     const int nj = (nf + 63) >> 6;
     const int mlanes = m < 64 ? m : 64;
-    const int G = 64 / mlanes;
+    const int G = 64 / mlanes;                         // lanes per bucket (a power of two whenever it is > 1)
     const int bl = lane / G, sub = lane % G;
-    const int step_q = 256 / B, step_r = 256 % B;      // bucket / offset of element 4 (lane + 64 j), advanced incrementally
-    const int q0 = (4 * lane) / B, r0 = (4 * lane) % B;
+    const int steps = (B + G - 1) / G;                 // elements each lane of a group handles
+    const int nrounds = (m + mlanes - 1) / mlanes;     // buckets each lane group handles
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -729,90 +697,97 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
         const int64_t b0 = c * m;
         const int64_t e0 = b0 * p.row;
         const f4* src = (const f4*)(p.x + e0);
-        f4 v[VMAX];
+        {
+            f4 v[VMAX];
 #pragma unroll
-        for (int j = 0; j < VMAX; ++j) {               // always-issued loads with a clamped address, as above
-            const int f = lane + 64 * j;
-            v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!prescaled) {
+            for (int j = 0; j < VMAX; ++j) {           // always-issued loads with a clamped address, as above
+                const int f = lane + 64 * j;
+                v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < VMAX; ++j) {
                 const int f = lane + 64 * j;
                 if (j < nj && f < nf) {
-                    if (prep_on) v[j] = prep4(v[j], pp);
+                    if (!prescaled && prep_on) v[j] = prep4(v[j], pp);
                     ((f4*)vals)[f] = v[j];
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int bb = bl; bb < m; bb += mlanes) {
-                const float* q = vals + bb * B;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // every lane runs every round and every step (clamped indices, masked stores): the level table of qdq_tab is
+        // fetched with ds_bpermute from the lanes of the own DPP row, which must all be active
+        for (int rd = 0; rd < nrounds; ++rd) {
+            const int bb_raw = bl + rd * mlanes;
+            const bool live = bb_raw < m;
+            const int bb = live ? bb_raw : m - 1;
+            float* q = vals + bb * B;
+            float a, b;
+            if (prescaled) {
+                a = p.alpha[b0 + bb]; b = p.beta[b0 + bb];
+            } else {
                 float mn = INFINITY, mx = -INFINITY;
-                int nan = 0;
-                for (int t = sub; t < B; t += G) {
-                    const float x = q[t];
-                    nan |= (x != x);
-                    mn = fminf(mn, x); mx = fmaxf(mx, x);
+                int t = sub;
+                for (; t + G < B; t += 2 * G) {         // two elements per step: one min3 / max3 each (NaN-propagating)
+                    const float x0 = q[t], x1 = q[t + G];
+                    mn = pmin(mn, pmin(x0, x1)); mx = pmax(mx, pmax(x0, x1));
                 }
+                if (t < B) { const float x0 = q[t]; mn = pmin(mn, x0); mx = pmax(mx, x0); }
                 for (int sft = 1; sft < G; sft <<= 1) {
-                    mn = fminf(mn, __shfl_xor(mn, sft));
-                    mx = fmaxf(mx, __shfl_xor(mx, sft));
-                    nan |= __shfl_xor(nan, sft);
+                    mn = pmin(mn, __shfl_xor(mn, sft));
+                    mx = pmax(mx, __shfl_xor(mx, sft));
                 }
-                if (nan) { mn = NAN; mx = NAN; }
-                float a, b;
                 alpha_beta(mn, mx, a, b);
-                if (sub == 0) {
-                    ab[bb] = make_float2(a, b);
+                if (live && sub == 0) {
                     if (p.alpha) p.alpha[b0 + bb] = a;
                     if (p.beta) p.beta[b0 + bb] = b;
                 }
             }
-        } else {
-            for (int bb = lane; bb < m; bb += 64) ab[bb] = make_float2(p.alpha[b0 + bb], p.beta[b0 + bb]);
+            // only the level of u is consumed by quantize-dequantize: bucket-invariant division (qd_common.h) when every
+            // bucket of this round is in its proven range
+            const bool fast = MODE == MODE_QDQ && !__any(!fastdiv_ok(a));
+            const int64_t eb = e0 + (int64_t)bb * B;   // first element of the bucket
+            auto body = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value;
+                const float y = FAST ? 1.0f / a : 0.0f; // RN(1/alpha), one IEEE division per bucket
+#pragma unroll 4
+                for (int i = 0; i < steps; ++i) {
+                    const int t_raw = sub + i * G;
+                    const bool ok = live && t_raw < B;
+                    const int t = t_raw < B ? t_raw : B - 1;
+                    const float x = q[t];
+                    const int64_t e = eb + t;
+                    float side = 0.0f, o;
+                    if (use_tab) {
+                        o = qdq_tab<FAST>(x, a, b, p.sm1, pp.mean, side, tab, y);
+                    } else {
+                        float rnd = 0.0f;
+                        if (MODE == MODE_QDQ && p.stochastic) {
+                            float r4[4];
+                            philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
+                            rnd = r4[e & 3];
+                        }
+                        o = transform<MODE, FAST>(p, T, x, a, b, pp.mean, rnd, side, y);
+                    }
+                    if (ok) {
+                        q[t] = o;
+                        store_side1<MODE>(p, e, side);
+                    }
+                }
+            };
+            if (fast) body(std::true_type{}); else body(std::false_type{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f4* dst = (f4*)(p.out + e0);
-        int q = q0, r = r0;
 #pragma unroll
         for (int j = 0; j < VMAX; ++j) {
             const int f = lane + 64 * j;
-            if (j < nj) {                                  // whole wave: lanes past the chunk work on their duplicate
-                const int qa = q < m ? q : m - 1, qb = q + 1 < m ? q + 1 : m - 1;
-                const float2 s0 = ab[qa];
-                const float2 s1 = ab[qb];
-                const int cut = B - r;                  // elements c >= cut of this float4 belong to bucket q + 1
-                const int64_t e = e0 + ((int64_t)f << 2);
-                const float a1 = 1 >= cut ? s1.x : s0.x, b1 = 1 >= cut ? s1.y : s0.y;
-                const float a2 = 2 >= cut ? s1.x : s0.x, b2 = 2 >= cut ? s1.y : s0.y;
-                const float a3 = 3 >= cut ? s1.x : s0.x, b3 = 3 >= cut ? s1.y : s0.y;
-                float side[4];
-                f4 o;
-                if (use_tab) {
-                    o.x = qdq_tab(v[j].x, s0.x, s0.y, p.sm1, pp.mean, side[0], tab);
-                    o.y = qdq_tab(v[j].y, a1, b1, p.sm1, pp.mean, side[1], tab);
-                    o.z = qdq_tab(v[j].z, a2, b2, p.sm1, pp.mean, side[2], tab);
-                    o.w = qdq_tab(v[j].w, a3, b3, p.sm1, pp.mean, side[3], tab);
-                } else {
-                    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
-                    o.x = transform<MODE>(p, T, v[j].x, s0.x, s0.y, pp.mean, rnd[0], side[0]);
-                    o.y = transform<MODE>(p, T, v[j].y, a1, b1, pp.mean, rnd[1], side[1]);
-                    o.z = transform<MODE>(p, T, v[j].z, a2, b2, pp.mean, rnd[2], side[2]);
-                    o.w = transform<MODE>(p, T, v[j].w, a3, b3, pp.mean, rnd[3], side[3]);
-                }
-                if (f < nf) {
-                    __builtin_nontemporal_store(o, dst + f);
-                    store_side4<MODE>(p, e, side);
-                }
-            }
-            q += step_q; r += step_r;
-            if (r >= B) { r -= B; ++q; }
+            if (j < nj && f < nf) __builtin_nontemporal_store(((const f4*)vals)[f], dst + f);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next chunk overwrites vals
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -1809,37 +1784,36 @@ __global__ __launch_bounds__(256) void k_multi_uniform(const QdTensorDesc* __res
             f4 v[V];
 #pragma unroll
             for (int j = 0; j < V; ++j) v[j] = ldg_nt(src + j * 16);   // masters: read once
-            float mn = fminf(fminf(v[0].x, v[0].y), fminf(v[0].z, v[0].w));
-            float mx = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+            float mn = pmin4(v[0]), mx = pmax4(v[0]);      // NaN-propagating
 #pragma unroll
-            for (int j = 1; j < V; ++j) {
-                mn = fminf(mn, fminf(fminf(v[j].x, v[j].y), fminf(v[j].z, v[j].w)));
-                mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
-            }
-            bool nan = false;
-#pragma unroll
-            for (int j = 0; j < V; ++j) nan |= has_nan4(v[j]);
+            for (int j = 1; j < V; ++j) { mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j])); }
             mn = row16_min(mn); mx = row16_max(mx);
-            if (group_any<16>(nan)) { mn = NAN; mx = NAN; }
             float a, b, lev;
             alpha_beta(mn, mx, a, b);
             f4* dst = (f4*)(p.out + lo) + l;
+            // rows of the wave that took this branch: all in the proven range -> bucket-invariant division (qd_common.h)
+            const bool fdiv = !__any(!fastdiv_ok(a));
+            auto body = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value;
+                const float y = FAST ? 1.0f / a : 0.0f;
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                f4 r;
-                if (use_tab) {                             // <= 16 levels: see k_bucket_vec (a DPP row is active as a whole here)
-                    r.x = qdq_tab(v[j].x, a, b, sm1, 0.0f, lev, tab);
-                    r.y = qdq_tab(v[j].y, a, b, sm1, 0.0f, lev, tab);
-                    r.z = qdq_tab(v[j].z, a, b, sm1, 0.0f, lev, tab);
-                    r.w = qdq_tab(v[j].w, a, b, sm1, 0.0f, lev, tab);
-                } else {
-                    r.x = qdq(v[j].x, a, b, sm1, 0.0f, lev);
-                    r.y = qdq(v[j].y, a, b, sm1, 0.0f, lev);
-                    r.z = qdq(v[j].z, a, b, sm1, 0.0f, lev);
-                    r.w = qdq(v[j].w, a, b, sm1, 0.0f, lev);
+                for (int j = 0; j < V; ++j) {
+                    f4 r;
+                    if (use_tab) {                         // <= 16 levels: see k_bucket_vec (a DPP row is active as a whole here)
+                        r.x = qdq_tab<FAST>(v[j].x, a, b, sm1, 0.0f, lev, tab, y);
+                        r.y = qdq_tab<FAST>(v[j].y, a, b, sm1, 0.0f, lev, tab, y);
+                        r.z = qdq_tab<FAST>(v[j].z, a, b, sm1, 0.0f, lev, tab, y);
+                        r.w = qdq_tab<FAST>(v[j].w, a, b, sm1, 0.0f, lev, tab, y);
+                    } else {
+                        r.x = qdq<FAST>(v[j].x, a, b, sm1, 0.0f, lev, y);
+                        r.y = qdq<FAST>(v[j].y, a, b, sm1, 0.0f, lev, y);
+                        r.z = qdq<FAST>(v[j].z, a, b, sm1, 0.0f, lev, y);
+                        r.w = qdq<FAST>(v[j].w, a, b, sm1, 0.0f, lev, y);
+                    }
+                    stg_nt(r, dst + j * 16);
                 }
-                stg_nt(r, dst + j * 16);
-            }
+            };
+            if (fdiv) body(std::true_type{}); else body(std::false_type{});
         } else {
             bucket_row16<MODE_QDQ>(p, nullptr, bkt, lo, hi, l, pp);
         }
@@ -1952,22 +1926,29 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     constexpr int kChunkV = 8;
     if (aligned && p.nb > 1 && (p.row & 3) == 0 && p.row <= (int64_t)kChunkV * 256) {
         const int64_t bq = p.row >> 2;
-        int m = 256;
-        while (m > 1 && (int64_t)m * bq > kChunkV * 64) m >>= 1;
+        // as many whole buckets as fit the chunk's kChunkV * 64 float4 (<= 256: the (alpha, beta) table), not the next power of
+        // two below it: bucket 36 fills 504 of the 512 float4 with m = 56 instead of 288 with m = 32.  Above 64 buckets a lane
+        // reduces whole buckets alone, below that 64 / m lanes share one, so m is then rounded down to a power of two.
+        int m = (int)((kChunkV * 64) / bq);
+        if (m > 256) m = 256;
+        if (m < 64) { int p2 = 1; while (p2 * 2 <= m) p2 *= 2; if (m < 48 || p2 == m) m = p2; else { /* 48..63 lanes, one bucket each */ } }
         const int64_t nchunks = nfull / m;
         if (nchunks > 0) {
-            const size_t lds = (size_t)2 * (kChunkV * 64 + 256) * sizeof(float2);       // two waves per block
+            const size_t lds = (size_t)2 * (kChunkV * 64 + 256 + 128) * sizeof(float2);   // two waves per block: pairs, (alpha, beta), 1/alpha
             const int blocks = blocks_for(nchunks, 2) + 1;                             // +1: the block that owns the tail
             hipLaunchKernelGGL((k_bucket_chunk<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
             return check_launch();
         }
     }
     if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row >= 4 && p.row * 4 <= (int64_t)kChunkV * 256) {
-        int m = 256;                                         // a multiple of 4: chunks start 16-byte aligned
-        while (m > 4 && (int64_t)m * p.row > kChunkV * 256) m >>= 1;
+        // a multiple of 4 (chunks start 16-byte aligned), as many buckets as fit kChunkV * 256 elements: bucket 33 fills
+        // 1980 of the 2048 elements with m = 60 instead of 1056 with m = 32
+        int m = (int)(((int64_t)kChunkV * 256) / p.row) & ~3;
+        if (m > 256) m = 256;
+        if (m < 64) { int p2 = 4; while (p2 * 2 <= m) p2 *= 2; if (m < 48 || p2 == m) m = p2; }
         const int64_t nchunks = nfull / m;
         if (nchunks > 0) {
-            const size_t lds = (size_t)2 * (kChunkV * 128 + 256) * sizeof(float2);
+            const size_t lds = (size_t)2 * (kChunkV * 128) * sizeof(float2);              // two waves: the staged chunk
             const int blocks = blocks_for(nchunks, 2) + 1;
             hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
             return check_launch();
@@ -1976,7 +1957,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row > 512 && p.row <= 1024) {     // four buckets per chunk, 16 float4 per lane
         const int64_t nchunks = nfull / 4;
         if (nchunks > 0) {
-            const size_t lds = (size_t)2 * (16 * 128 + 256) * sizeof(float2);
+            const size_t lds = (size_t)2 * (16 * 128) * sizeof(float2);
             const int blocks = blocks_for(nchunks, 2) + 1;
             hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds, st, p, 4, nchunks);
             return check_launch();
@@ -2290,7 +2271,18 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
             if (k <= 4) QD_PG(4, IDXB, BK, 4, false)                                                                \
             else if (!big) QD_PG(0, IDXB, BK, 4, false)                                                             \
             else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
-            else QD_PG(0, IDXB, BK, 8, true)                                                                        \
+            else if (big_u == 8) QD_PG(0, IDXB, BK, 8, true)                                                        \
+            else if (big_u == 16) QD_PG(0, IDXB, BK, 16, true)                                                      \
+            else QD_PG(0, IDXB, BK, 32, true)                                                                       \
+        }
+        // A table above 64 KiB leaves ONE block per CU (4, 2 or 1 waves): the only way to keep enough bytes in flight
+        // is more loads per lane -- each wave has a quarter of a SIMD's register file or more to itself.  U float4 of g
+        // (+ their packed indices) per lane: 16 with four waves, 32 with two or one (80 KB in flight per CU either way).
+        int big_u = threads == 256 ? 16 : 32;
+        {
+            static int forced = -1;
+            if (forced < 0) { const char* e = getenv("QD_PG_U"); forced = e ? atoi(e) : 0; }
+            if (forced == 8 || forced == 16 || forced == 32) big_u = forced;
         }
         if (idx_bytes == 8) { if (nb > 1) QD_PG_K(8, true) else QD_PG_K(8, false) }
         else { if (nb > 1) QD_PG_K(1, true) else QD_PG_K(1, false) }

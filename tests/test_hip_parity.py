@@ -780,3 +780,53 @@ def test_single_bucket_fused_under_contention_two_streams(fused_mode):
     # the barrier slots were re-armed: a later launch still works
     q, _ = quantization.uniformQuantization(xd[0], 16)
     assert np.array_equal(host(q), want[0])
+
+
+# ------------------------------------------------------------------------------ bucket-invariant division (round 2)
+@pytest.mark.parametrize('bucket', [256, 64, 512, 100, 36, 33, 50, 7, 1000])
+def test_quantize_bit_exact_at_extreme_scales(bucket):
+    """The quantize kernels divide by the bucket's alpha through y = RN(1/alpha) and two FMAs when alpha is in
+    [2^-60, 2^100] (exact there, qd_common.h) and by IEEE division otherwise; numerators below 2^-100 only ever
+    yield level 0.  Exercise both sides of every boundary: tiny / huge / denormal scales, buckets that mix them,
+    constant buckets, zeros next to denormals -- q, alpha, beta bit-exact against the C oracle for 16 and 4 levels,
+    deterministic, plus the stochastic branch against the Philox restatement."""
+    import quantization.quant_functions as qf
+    rng = np.random.RandomState(bucket)
+    n = 40 * 2048 + 3
+    base = rng.randn(n).astype(np.float32)
+    scales = [1.0, 1e-3, 2.0 ** -58, 2.0 ** -61, 2.0 ** -70, 1e-30, 1e-37, 1e-39, 1e-43, 2.0 ** 99, 2.0 ** 101, 1e30, 3e37]
+    cases = [(base * np.float32(sc)).astype(np.float32) for sc in scales]
+    mixed = base.copy()
+    per = np.repeat(np.array(scales * 400, dtype=np.float64)[: (n + 255) // 256], 256)[:n]
+    mixed = (mixed.astype(np.float64) * per).astype(np.float32)              # a different scale every 256 elements
+    cases.append(mixed)
+    sparse = np.where(rng.rand(n) < 0.7, 0.0, base * 1e-41).astype(np.float32)   # zeros next to denormals
+    cases.append(sparse)
+    tinyspread = (np.abs(base) * np.float32(1e-36) + np.float32(1.0)).astype(np.float32)   # alpha < 1e-10 -> 1, constant-ish
+    cases.append(tinyspread)
+    offset = (base * np.float32(2.0 ** -59) + np.float32(3.0)).astype(np.float32)
+    cases.append(offset)
+    for ci, x in enumerate(cases):
+        for s in (16, 4, 256):
+            want = oc.uniform_quantize(x, s, bucket, want_idx=False, want_lev=False)
+            q, sf = quantization.uniformQuantization(dev(x), s, bucket_size=bucket)
+            got = host(q)
+            assert np.array_equal(got, want['q'], equal_nan=True), (bucket, ci, s, int(np.sum(got != want['q'])))
+            assert np.array_equal(host(sf.alpha).reshape(-1), want['alpha'], equal_nan=True)
+        seed = qf.next_stochastic_seed(peek=True)
+        qs, _ = quantization.uniformQuantization(dev(x), 16, stochastic_rounding=True, bucket_size=bucket)
+        nb, row, padded = onp.bucket_geometry(n, bucket)
+        rand = np.zeros(padded, np.float32)
+        rand[:n] = onp.philox4x32_7_uniform(seed, n)
+        ws = onp.uniform_quantize_stochastic(x, 16, rand, bucket)
+        assert np.array_equal(host(qs), ws['q'], equal_nan=True), (bucket, ci, 'stochastic')
+
+
+def test_multi_tensor_bit_exact_at_extreme_scales():
+    from quantized_distillation_amd.multi_tensor import MultiTensorQuantizer
+    rng = np.random.RandomState(5)
+    xs = [(rng.randn(4096 + 77 * i) * sc).astype(np.float32) for i, sc in
+          enumerate([1.0, 2.0 ** -59, 2.0 ** -62, 1e-38, 1e-42, 2.0 ** 100, 2.0 ** 102, 1e-3])]
+    mt = MultiTensorQuantizer([dev(x) for x in xs], 16, 256)
+    for x, q in zip(xs, mt.quantize()):
+        assert np.array_equal(host(q), oc.uniform_quantize(x, 16, 256, want_idx=False, want_lev=False)['q'], equal_nan=True)
