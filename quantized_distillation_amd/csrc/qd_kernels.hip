@@ -1524,6 +1524,107 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
     }
 }
 
+// stage 1 for tables of 128 KiB (k > 128 points): TWO thread groups share one set of lane-private columns.
+// The table [k][C] must fit the 160 KiB of LDS, so C = 128 / 64 columns for k <= 256 / 512, and with one lane per column
+// that left 2 / 1 waves per CU: every wave paid the LDS round trip of each float4 (read 4 bins, add, write) AND its ~40
+// VALU instructions (products, duplicate merging) back to back -- 121 / 305 us for 64 Mi elements.  Here the block has
+// 2 C lanes: lane t and lane t + C own the SAME column but never touch it at the same time -- the groups alternate
+// between a table phase (read-add-write of a prepared batch) and a preparation phase (loads, products, duplicate merging
+// of the next batch), separated by block barriers.  The VALU half of one group overlaps the LDS half of the other and
+// twice as many loads are in flight: 104 / 234 us.  Still no atomics, and deterministic: fixed columns, fixed phase
+// order, fixed fold.  (Issuing a batch's loads one phase ahead of its preparation should hide the HBM latency that now
+// dominates the preparation phase, but the double-buffered batch takes 195-256 VGPRs: 110 us, and 632 us with the
+// spills of the int64-index variant.  With four waves per CU already -- k <= 128 -- sharing loses: 74 vs 67 us.)
+template <int IDXB, bool BUCKETED, int U>
+__global__ __launch_bounds__(512) void k_point_grad_shared(const float* g, const void* idx, const float* alpha, int64_t n,
+                                                           int row_shift, int k, float* part /* [grid][k] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [k][C]
+    const int C = blockDim.x >> 1;
+    const int grp = threadIdx.x >= C ? 1 : 0;
+    float* col = lds + (threadIdx.x - grp * C);
+    for (int j = threadIdx.x; j < k * C; j += blockDim.x) lds[j] = 0.0f;
+    const float a_single = BUCKETED ? 0.0f : alpha[0];
+    const int64_t n4 = n >> 2;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const int64_t iters = (n4 + (int64_t)U * nth - 1) / ((int64_t)U * nth);   // the same for every lane: barriers inside
+    int id[U][4];
+    float sm[U][4];
+    auto prepare = [&](int64_t it) {
+        f4 gv[U]; uint32_t pk[U]; l2 p0[U], p1[U]; float a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i_raw = tid + ((int64_t)it * U + u) * nth;
+            const int64_t i = i_raw < n4 ? i_raw : (n4 > 0 ? n4 - 1 : 0);  // always-issued loads, clamped address
+            gv[u] = __builtin_nontemporal_load((const f4*)g + i);
+            if (IDXB == 8) {
+                p0[u] = __builtin_nontemporal_load((const l2*)idx + 2 * i);
+                p1[u] = __builtin_nontemporal_load((const l2*)idx + 2 * i + 1);
+            } else {
+                pk[u] = __builtin_nontemporal_load((const uint32_t*)idx + i);
+            }
+            a[u] = BUCKETED ? alpha[(i << 2) >> row_shift] : a_single;
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // all loads of the batch in flight together
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i_raw = tid + ((int64_t)it * U + u) * nth;
+            const bool live = i_raw < n4;
+            if (IDXB == 8) {
+                id[u][0] = (int)p0[u].x; id[u][1] = (int)p0[u].y; id[u][2] = (int)p1[u].x; id[u][3] = (int)p1[u].y;
+            } else {
+                id[u][0] = pk[u] & 255; id[u][1] = (pk[u] >> 8) & 255; id[u][2] = (pk[u] >> 16) & 255; id[u][3] = pk[u] >> 24;
+            }
+            const float z = 0.0f;
+            const float m0 = live ? gv[u].x * a[u] : z, m1 = live ? gv[u].y * a[u] : z;    // one fp32 multiply each, :495
+            const float m2 = live ? gv[u].z * a[u] : z, m3 = live ? gv[u].w * a[u] : z;
+            const bool e01 = id[u][0] == id[u][1], e02 = id[u][0] == id[u][2], e03 = id[u][0] == id[u][3];
+            const bool e12 = id[u][1] == id[u][2], e13 = id[u][1] == id[u][3], e23 = id[u][2] == id[u][3];
+            // every element whose index matches gets the same fixed-order sum: equal addresses are written with equal values
+            sm[u][0] = ((m0 + (e01 ? m1 : z)) + (e02 ? m2 : z)) + (e03 ? m3 : z);
+            sm[u][1] = (((e01 ? m0 : z) + m1) + (e12 ? m2 : z)) + (e13 ? m3 : z);
+            sm[u][2] = (((e02 ? m0 : z) + (e12 ? m1 : z)) + m2) + (e23 ? m3 : z);
+            sm[u][3] = (((e03 ? m0 : z) + (e13 ? m1 : z)) + (e23 ? m2 : z)) + m3;
+        }
+    };
+    auto update = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float* a0 = col + id[u][0] * C; float* a1 = col + id[u][1] * C;
+            float* a2 = col + id[u][2] * C; float* a3 = col + id[u][3] * C;
+            const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
+            *a0 = c0 + sm[u][0]; *a1 = c1 + sm[u][1]; *a2 = c2 + sm[u][2]; *a3 = c3 + sm[u][3];
+        }
+    };
+    // group 0: update(i) | prepare(i + 1) ...      group 1: prepare(i) | update(i) ...
+    if (grp == 0 && iters > 0) prepare(0);
+    __syncthreads();                                        // table zeroed, group 0 prepared
+    for (int64_t it = 0; it < iters; ++it) {
+        if (grp == 0) update(); else prepare(it);
+        __syncthreads();
+        if (grp == 1) update(); else if (it + 1 < iters) prepare(it + 1);
+        __syncthreads();
+    }
+    // n % 4 leftover elements: group 0's first lanes of block 0, after the last table phase
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+        const int64_t e = (n4 << 2) + threadIdx.x;
+        const int ide = IDXB == 8 ? (int)((const int64_t*)idx)[e] : (int)((const uint8_t*)idx)[e];
+        col[ide * C] += g[e] * (BUCKETED ? alpha[e >> row_shift] : a_single);
+    }
+    __syncthreads();
+    // 4 threads per bin, C/4 columns each, rotated start (bank-conflict free), then a fixed fold
+    const int quarter = C >> 2;
+    for (int t = threadIdx.x; t < ((k * 4 + 3) & ~3); t += blockDim.x) {
+        const int j = t >> 2, q = t & 3;
+        float acc = 0.0f;
+        if (j < k)
+            for (int c = 0; c < quarter; ++c) acc += lds[j * C + q * quarter + ((c + j) & (quarter - 1))];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (q == 0 && j < k) part[(int64_t)blockIdx.x * k + j] = acc;
+    }
+}
+
 // stage 1 (generic path): any alignment / bucket size / k <= 1024; LDS table bins[k][C] with
 // atomics (lanes that share a column and an index collide; correct, order of those not fixed).
 __global__ __launch_bounds__(256) void k_point_grad_generic(const float* g, const void* idx, int idx_bytes,
@@ -2271,14 +2372,23 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
             if (k <= 4) QD_PG(4, IDXB, BK, 4, false)                                                                \
             else if (!big) QD_PG(0, IDXB, BK, 4, false)                                                             \
             else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
+            else if (pg_shared && threads < 256) {          /* k > 128: two groups per column set */                \
+                auto kern = k_point_grad_shared<IDXB, BK, 8>;                                                       \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(2 * threads), lds_bytes, st, g, idx, alpha, n, row_shift, k, \
+                                   w.pg_part);                                                                      \
+            }                                                                                                       \
             else if (big_u == 8) QD_PG(0, IDXB, BK, 8, true)                                                        \
             else if (big_u == 16) QD_PG(0, IDXB, BK, 16, true)                                                      \
             else QD_PG(0, IDXB, BK, 32, true)                                                                       \
         }
+        static int pg_shared = -1;                           // QD_PG_SHARED=0: one lane per column (A/B measurements)
+        if (pg_shared < 0) { const char* e = getenv("QD_PG_SHARED"); pg_shared = (e && e[0] == '0') ? 0 : 1; }
         // A table above 64 KiB leaves ONE block per CU (4, 2 or 1 waves): the only way to keep enough bytes in flight
         // is more loads per lane -- each wave has a quarter of a SIMD's register file or more to itself.  U float4 of g
-        // (+ their packed indices) per lane: 16 with four waves, 32 with two or one (80 KB in flight per CU either way).
-        int big_u = threads == 256 ? 16 : 32;
+        // (+ their packed indices) per lane.  Measured (k = 128 / 256): U = 8: 66.6 / 121 us, 16: 68.5 / 110, 32: 79 / 119 --
+        // the waves are bound by their own VALU + LDS round trips, not by HBM latency, so this only helps a little.
+        int big_u = threads == 256 ? 8 : 16;
         {
             static int forced = -1;
             if (forced < 0) { const char* e = getenv("QD_PG_U"); forced = e ? atoi(e) : 0; }
