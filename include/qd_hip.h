@@ -5,7 +5,8 @@
  * `quantization` (quantization/__init__.py:4-8), a chain of unfused torch ops.  Each entry point
  * below replaces the chain of reference ops cited next to it (paths relative to the reference
  * root); the Python package `quantization` shipped in this repository keeps the reference's
- * signatures and binds these symbols with ctypes.
+ * signatures and binds these symbols with ctypes and, for the per-call entry points, with a small
+ * CPython/ATen module (csrc/qd_torch_glue.cpp).
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless it says "host";
