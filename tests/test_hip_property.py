@@ -36,13 +36,24 @@ def make(n, seed, kind):
         x = np.full(n, 0.25)                                       # alpha guard
     elif kind == 4:
         x = rng.standard_cauchy(n)                                 # heavy tails / huge ranges
-    else:
+    elif kind == 5:
         x = rng.rand(n) * 1e-30                                    # tiny magnitudes (alpha < 1e-10 -> 1)
-    return x.astype(np.float32)
+    elif kind == 6:
+        # any power-of-two scale: both sides of the bucket-invariant-division range [2^-60, 2^100], denormals, near-overflow
+        with np.errstate(over='ignore', under='ignore'):
+            x = np.ldexp(rng.randn(n), int(rng.randint(-148, 122)))
+    elif kind == 7:
+        # a different scale every few hundred elements (buckets of one wave fall on both sides of the range)
+        with np.errstate(over='ignore', under='ignore'):
+            e = np.repeat(rng.randint(-140, 120, size=n // 97 + 1), 97)[:n]
+            x = np.ldexp(rng.randn(n), e)
+    else:
+        x = np.where(rng.rand(n) < 0.6, 0.0, rng.randn(n) * 1e-40) + (rng.rand(n) < 0.001) * 1.0   # zeros, denormals, a few ones
+    return np.nan_to_num(x.astype(np.float32), nan=0.0, posinf=3e38, neginf=-3e38)
 
 
 @settings(max_examples=60 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
-@given(n=sizes, bucket=buckets, s=levels, seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 5),
+@given(n=sizes, bucket=buckets, s=levels, seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 8),
        clamp=st.sampled_from([False, False, 0.5, 2.0]))
 def test_uniform_matches_oracle(n, bucket, s, seed, kind, clamp):
     x = make(n, seed, kind)
