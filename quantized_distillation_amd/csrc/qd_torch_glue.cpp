@@ -88,7 +88,8 @@ void require_device_f32(const at::Tensor& t, const char* what) {
 
 inline int64_t num_buckets(int64_t n, int64_t bucket) { return (bucket <= 0 || n < bucket) ? 1 : (n + bucket - 1) / bucket; }
 
-// uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place) -> (q, ab, mean | None)
+// uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place)
+//   -> (q, ab, mean | None, n, x_read)
 //   ab: [2, nb, 1] (bucket > 0) or [2, 1] (bucket == 0): row 0 = alpha, row 1 = beta, shaped as the reference's
 //   min/max(keepdim=True) results (quant_functions.py:85-92).  One qd_uniform_f32 launch.
 PyObject* glue_uniform(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
@@ -144,7 +145,7 @@ PyObject* glue_uniform(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     } else if (subtract_mean) {
         mean = empty_f32({1}, dev);
     }
-    PyObject* out = PyTuple_New(3);
+    PyObject* out = PyTuple_New(5);
     PyTuple_SET_ITEM(out, 0, THPVariable_Wrap(q));
     PyTuple_SET_ITEM(out, 1, THPVariable_Wrap(ab));
     if (mean.defined()) {
@@ -152,6 +153,13 @@ PyObject* glue_uniform(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     } else {
         Py_INCREF(Py_None);
         PyTuple_SET_ITEM(out, 2, Py_None);
+    }
+    PyTuple_SET_ITEM(out, 3, PyLong_FromLongLong(n));
+    if (x.is_same(x0)) {                                   // the tensor that was read (the input itself when contiguous)
+        Py_INCREF(args[0]);
+        PyTuple_SET_ITEM(out, 4, args[0]);
+    } else {
+        PyTuple_SET_ITEM(out, 4, THPVariable_Wrap(x));
     }
     return out;
     END_HANDLE_TH_ERRORS
@@ -301,7 +309,7 @@ PyObject* glue_host_cost_probe(PyObject*, PyObject* const* args, Py_ssize_t narg
 
 PyMethodDef methods[] = {
     {"uniform", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_uniform)), METH_FASTCALL,
-     "uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place) -> (q, ab, mean)"},
+     "uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place) -> (q, ab, mean, n, x_read)"},
     {"nearest", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_nearest)), METH_FASTCALL,
      "nearest(x, prescaled, points, assign_mode, n, bucket, alpha, beta, mean, clamp, max_element, idx_bytes) -> (q, idx)"},
     {"point_grad", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_point_grad)), METH_FASTCALL,

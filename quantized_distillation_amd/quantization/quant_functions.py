@@ -66,7 +66,7 @@ class ScalingFunction(object):
     # is on the host-side critical path of the drop-in.
     tol_diff_zero = 1e-10
     mean_tensor = None
-    original_tensor_size = None
+    _shape = None
     norm_scaling = None
     tensor_sign = None
     _n = None
@@ -116,6 +116,17 @@ class ScalingFunction(object):
     @beta.setter
     def beta(self, v):
         self._beta = v
+
+    @property
+    def original_tensor_size(self):
+        """Shape of the tensor that was scaled (ref: :76-77); taken from the retained source when not stored."""
+        if self._shape is None and self._arg_source is not None:
+            self._shape = self._arg_source.shape
+        return self._shape
+
+    @original_tensor_size.setter
+    def original_tensor_size(self, v):
+        self._shape = v
 
     @property
     def original_tensor_length(self):
@@ -210,6 +221,8 @@ class ScalingFunction(object):
         shape = (1,) if self.bucket_size is None else (nb, 1)
         self._idx_min_rows = out[0].view(*shape)
         self._idx_max_rows = out[1].view(*shape)
+        if self._shape is None:
+            self._shape = t.shape
         self._arg_source = None
 
     @property
@@ -301,18 +314,51 @@ class ScalingFunction(object):
         return out.view(self.original_tensor_size)
 
 
+_glue_uniform = None
+_new_object = object.__new__
+
+
 def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding=False,
                         max_element=False, subtract_mean=False, bucket_size=None, modify_in_place=False):
     """k-level uniform quantize-dequantize ("fake quantization") of `tensor` with `s` levels.
     Returns (quantized tensor of the same shape, ScalingFunction).  ref: :155-194.
 
     One fused kernel (K1) for bucketed tensors -- per-bucket min/max, alpha/beta, scale, round
-    half to even, rescale; without buckets one kernel too when the tensor fits on chip, three
-    small launches otherwise.  The input is left untouched unless modify_in_place=True.
+    half to even, rescale; without buckets one kernel too when the tensor is small enough for the
+    register-resident kernel, reduce + apply otherwise.  The input is left untouched unless
+    modify_in_place=True.
 
     The call goes through the CPython/ATen binding of the C ABI (csrc/qd_torch_glue.cpp): output
     allocation, current stream and the launch happen in one native call, and the returned
-    ScalingFunction materialises alpha / beta / the arg indices only when they are read."""
+    ScalingFunction materialises alpha / beta / sizes / the arg indices only when they are read.
+    The common configuration of the training loops (linear scaling, no clamp, no mean, out of
+    place; ref: conv_forward_model.py:216-221) takes a path with the argument checks inlined --
+    this function is called once per parameter tensor per step."""
+    global _glue_uniform
+    if _glue_uniform is None:
+        _glue_uniform = _lib.glue().uniform
+    if (type_of_scaling == 'linear' and max_element is False and not modify_in_place
+            and (bucket_size is None or (type(bucket_size) is int and bucket_size > 0))
+            and type(s) is int and s >= 2):
+        q, ab, mean, n, x_read = _glue_uniform(tensor, s, bucket_size or 0, False, 0.0, stochastic_rounding,
+                                               next_stochastic_seed() if stochastic_rounding else 0, subtract_mean, False)
+        sf = _new_object(ScalingFunction)
+        d = sf.__dict__
+        d['type_scaling'] = 'linear'
+        d['max_element'] = False
+        d['subtract_mean'] = subtract_mean
+        d['bucket_size'] = bucket_size
+        d['modify_in_place'] = True                                                  # as the reference, :166-167
+        d['_n'] = n
+        d['_ab'] = ab
+        d['_arg_source'] = x_read
+        d['_arg_version'] = tensor._version
+        if mean is not None:
+            d['_mean_buf'] = mean
+            d['mean_tensor'] = mean.view(())                                         # 0-dim, ref: :67
+        else:
+            d['mean_tensor'] = 0                                                     # ref: :70
+        return q, sf
     sf = ScalingFunction(type_of_scaling, max_element, subtract_mean, bucket_size, True)    # as the reference, :166-167
     if int(s) != s or s < 2:
         raise ValueError('s must be an integer >= 2')
@@ -331,11 +377,11 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
         with torch.cuda.device(tensor.device):
             sf._note_arg_source(tensor, overwritten=True)
     clamp = max_element is not False
-    q, ab, mean = _lib.glue().uniform(tensor, int(s), bucket_size or 0, clamp, float(max_element) if clamp else 0.0,
-                                      stochastic_rounding, next_stochastic_seed() if stochastic_rounding else 0,
-                                      subtract_mean, modify_in_place)
+    q, ab, mean, n, x_read = _glue_uniform(tensor, int(s), bucket_size or 0, clamp, float(max_element) if clamp else 0.0,
+                                           stochastic_rounding, next_stochastic_seed() if stochastic_rounding else 0,
+                                           subtract_mean, modify_in_place)
     sf.original_tensor_size = q.shape
-    sf._n = q.numel()
+    sf._n = n
     sf._ab = ab
     if mean is not None:
         sf._mean_buf = mean
@@ -343,7 +389,7 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     else:
         sf.mean_tensor = 0                                                           # ref: :70
     if not modify_in_place:
-        sf._arg_source = tensor if tensor.is_contiguous() else tensor.contiguous()
+        sf._arg_source = x_read
         sf._arg_version = tensor._version
     return q, sf
 
@@ -408,7 +454,8 @@ def _points_on(points, device):
         points = torch.tensor(points, dtype=torch.float32)                            # ref: :238-239
     if not isinstance(points, torch.Tensor):
         points = torch.as_tensor(points, dtype=torch.float32)
-    points = points.detach()
+    if points.requires_grad:
+        points = points.detach()
     if points.dtype != torch.float32 or points.device != device or not points.is_contiguous():
         points = points.to(device=device, dtype=torch.float32).contiguous()
     return points
@@ -592,8 +639,10 @@ class nonUniformQuantization_variable(object):
             n = sf.original_tensor_length
             q, idx = _nearest(u, True, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf,
                               0, 0.0, 1 if numPoints <= 256 else 8)
-            q = q.view(sf.original_tensor_size)
-            idx = idx.view(sf.original_tensor_size)
+            shape = sf.original_tensor_size
+            if len(shape) != 1:
+                q = q.view(shape)
+                idx = idx.view(shape)
         else:
             q, idx, sf = nonUniformQuantization(
                 inputTensor, listQuantizationPoints, modify_in_place=self.modifyInPlace,
