@@ -1524,34 +1524,37 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
     }
 }
 
-// stage 1 for tables of 128 KiB (k > 128 points): TWO thread groups share one set of lane-private columns.
-// The table [k][C] must fit the 160 KiB of LDS, so C = 128 / 64 columns for k <= 256 / 512, and with one lane per column
-// that left 2 / 1 waves per CU: every wave paid the LDS round trip of each float4 (read 4 bins, add, write) AND its ~40
-// VALU instructions (products, duplicate merging) back to back -- 121 / 305 us for 64 Mi elements.  Here the block has
-// 2 C lanes: lane t and lane t + C own the SAME column but never touch it at the same time -- the groups alternate
-// between a table phase (read-add-write of a prepared batch) and a preparation phase (loads, products, duplicate merging
-// of the next batch), separated by block barriers.  The VALU half of one group overlaps the LDS half of the other and
-// twice as many loads are in flight: 104 / 234 us.  Still no atomics, and deterministic: fixed columns, fixed phase
-// order, fixed fold.  (Issuing a batch's loads one phase ahead of its preparation should hide the HBM latency that now
-// dominates the preparation phase, but the double-buffered batch takes 195-256 VGPRs: 110 us, and 632 us with the
-// spills of the int64-index variant.  With four waves per CU already -- k <= 128 -- sharing loses: 74 vs 67 us.)
-template <int IDXB, bool BUCKETED, int U>
-__global__ __launch_bounds__(512) void k_point_grad_shared(const float* g, const void* idx, const float* alpha, int64_t n,
-                                                           int row_shift, int k, float* part /* [grid][k] */) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];       // [k][C]
-    const int C = blockDim.x >> 1;
-    const int grp = threadIdx.x >= C ? 1 : 0;
-    float* col = lds + (threadIdx.x - grp * C);
+// stage 1 for k > 64 points: G waves take TURNS on one set of 64 lane-private columns.
+// With one lane per column a [k][256 / 128 / 64] table (k <= 128 / 256 / 512) fills the LDS and leaves 4 / 2 / 1 waves per
+// CU, each paying the LDS round trip of every float4 (read 4 bins, add, write) AND its ~40 VALU instructions back to
+// back: 66 / 121 / 305 us for 64 Mi elements.  (An intermediate form -- two thread groups sharing the columns and
+// alternating table and preparation phases between block barriers -- reached 104 / 234 us at k = 256 / 512: the phases
+// are as long as the HBM latency of a batch.)
+// What serialises is only the table phase of a batch (U round trips of read-4-bins / add / write, ~1 k cycles); the rest --
+// HBM latency of the batch's loads (~5 k cycles), products and duplicate merging (~1.3 k) -- is private to a wave.  So G
+// single-wave groups share a [k][64] table (64 KiB at k = 256: two blocks per CU, eight waves instead of two) and pass a
+// turn token round robin through LDS: a wave issues the loads of batch i+2, waits for its turn, updates the table with
+// batch i, hands the token on, and prepares batch i+1 while the other waves take their turns.  No block barriers in the
+// loop, no atomics on the table, and deterministic: the update order is fixed (wave 0, 1, ..., G-1, batch by batch).
+template <int IDXB, bool BUCKETED, int U, int G>
+__global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, const void* idx, const float* alpha, int64_t n,
+                                                            int row_shift, int k, float* part /* [grid][k] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [k][64]
+    __shared__ int turn;
+    constexpr int C = 64;
+    const int grp = threadIdx.x >> 6;
+    float* col = lds + (threadIdx.x & 63);
     for (int j = threadIdx.x; j < k * C; j += blockDim.x) lds[j] = 0.0f;
+    if (threadIdx.x == 0) turn = 0;
     const float a_single = BUCKETED ? 0.0f : alpha[0];
     const int64_t n4 = n >> 2;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    const int64_t iters = (n4 + (int64_t)U * nth - 1) / ((int64_t)U * nth);   // the same for every lane: barriers inside
+    const int64_t iters = (n4 + (int64_t)U * nth - 1) / ((int64_t)U * nth);   // the same for every wave: the token must circulate
     int id[U][4];
     float sm[U][4];
-    auto prepare = [&](int64_t it) {
-        f4 gv[U]; uint32_t pk[U]; l2 p0[U], p1[U]; float a[U];
+    f4 gv[U]; uint32_t pk[U]; l2 p0[U], p1[U]; float al[U];             // the raw batch in flight
+    auto issue = [&](int64_t it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i_raw = tid + ((int64_t)it * U + u) * nth;
@@ -1563,9 +1566,11 @@ __global__ __launch_bounds__(512) void k_point_grad_shared(const float* g, const
             } else {
                 pk[u] = __builtin_nontemporal_load((const uint32_t*)idx + i);
             }
-            a[u] = BUCKETED ? alpha[(i << 2) >> row_shift] : a_single;
+            al[u] = BUCKETED ? alpha[(i << 2) >> row_shift] : a_single;
         }
-        __builtin_amdgcn_sched_barrier(0);                  // all loads of the batch in flight together
+        __builtin_amdgcn_sched_barrier(0);                  // issued here, not sunk to the first use
+    };
+    auto compute = [&](int64_t it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i_raw = tid + ((int64_t)it * U + u) * nth;
@@ -1576,8 +1581,8 @@ __global__ __launch_bounds__(512) void k_point_grad_shared(const float* g, const
                 id[u][0] = pk[u] & 255; id[u][1] = (pk[u] >> 8) & 255; id[u][2] = (pk[u] >> 16) & 255; id[u][3] = pk[u] >> 24;
             }
             const float z = 0.0f;
-            const float m0 = live ? gv[u].x * a[u] : z, m1 = live ? gv[u].y * a[u] : z;    // one fp32 multiply each, :495
-            const float m2 = live ? gv[u].z * a[u] : z, m3 = live ? gv[u].w * a[u] : z;
+            const float m0 = live ? gv[u].x * al[u] : z, m1 = live ? gv[u].y * al[u] : z;  // one fp32 multiply each, :495
+            const float m2 = live ? gv[u].z * al[u] : z, m3 = live ? gv[u].w * al[u] : z;
             const bool e01 = id[u][0] == id[u][1], e02 = id[u][0] == id[u][2], e03 = id[u][0] == id[u][3];
             const bool e12 = id[u][1] == id[u][2], e13 = id[u][1] == id[u][3], e23 = id[u][2] == id[u][3];
             // every element whose index matches gets the same fixed-order sum: equal addresses are written with equal values
@@ -1586,6 +1591,7 @@ __global__ __launch_bounds__(512) void k_point_grad_shared(const float* g, const
             sm[u][2] = (((e02 ? m0 : z) + (e12 ? m1 : z)) + m2) + (e23 ? m3 : z);
             sm[u][3] = (((e03 ? m0 : z) + (e13 ? m1 : z)) + (e23 ? m2 : z)) + m3;
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto update = [&]() {
 #pragma unroll
@@ -1596,24 +1602,34 @@ __global__ __launch_bounds__(512) void k_point_grad_shared(const float* g, const
             *a0 = c0 + sm[u][0]; *a1 = c1 + sm[u][1]; *a2 = c2 + sm[u][2]; *a3 = c3 + sm[u][3];
         }
     };
-    // group 0: update(i) | prepare(i + 1) ...      group 1: prepare(i) | update(i) ...
-    if (grp == 0 && iters > 0) prepare(0);
-    __syncthreads();                                        // table zeroed, group 0 prepared
-    for (int64_t it = 0; it < iters; ++it) {
-        if (grp == 0) update(); else prepare(it);
-        __syncthreads();
-        if (grp == 1) update(); else if (it + 1 < iters) prepare(it + 1);
-        __syncthreads();
+    if (iters > 0) {
+        issue(0);
+        compute(0);
+        if (iters > 1) issue(1);
     }
-    // n % 4 leftover elements: group 0's first lanes of block 0, after the last table phase
+    __syncthreads();                                        // table zeroed, token at wave 0
+    for (int64_t it = 0; it < iters; ++it) {
+        while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        update();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's table writes are done before the token moves
+        if ((threadIdx.x & 63) == 0)
+            __hip_atomic_store(&turn, grp + 1 == G ? 0 : grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (it + 1 < iters) {
+            compute(it + 1);
+            if (it + 2 < iters) issue(it + 2);
+        }
+    }
+    __syncthreads();
+    // n % 4 leftover elements: wave 0's first lanes of block 0, after the last table phase
     if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
         const int64_t e = (n4 << 2) + threadIdx.x;
         const int ide = IDXB == 8 ? (int)((const int64_t*)idx)[e] : (int)((const uint8_t*)idx)[e];
         col[ide * C] += g[e] * (BUCKETED ? alpha[e >> row_shift] : a_single);
     }
     __syncthreads();
-    // 4 threads per bin, C/4 columns each, rotated start (bank-conflict free), then a fixed fold
-    const int quarter = C >> 2;
+    // 4 threads per bin, 16 columns each, rotated start (bank-conflict free), then a fixed fold
+    constexpr int quarter = C >> 2;
     for (int t = threadIdx.x; t < ((k * 4 + 3) & ~3); t += blockDim.x) {
         const int j = t >> 2, q = t & 3;
         float acc = 0.0f;
@@ -2372,18 +2388,34 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
             if (k <= 4) QD_PG(4, IDXB, BK, 4, false)                                                                \
             else if (!big) QD_PG(0, IDXB, BK, 4, false)                                                             \
             else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
-            else if (pg_shared && threads < 256) {          /* k > 128: two groups per column set */                \
-                auto kern = k_point_grad_shared<IDXB, BK, 8>;                                                       \
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-                hipLaunchKernelGGL(kern, dim3(blocks), dim3(2 * threads), lds_bytes, st, g, idx, alpha, n, row_shift, k, \
-                                   w.pg_part);                                                                      \
+            else if (pg_turns) {                             /* k > 64: four waves take turns on 64 columns */      \
+                const size_t tl = (size_t)k * 64 * sizeof(float);                                                   \
+                int per_cu_t = (int)((160 * 1024) / (tl + 64));   /* LDS; the 142-163 VGPRs allow 3 blocks per CU */  \
+                if (per_cu_t > pg_bpc) per_cu_t = pg_bpc;                                                            \
+                int tb = num_cus() * per_cu_t;                                                                       \
+                if (tb > blocks_all) tb = blocks_all;                                                                \
+                if (tb > (int)max_rows) tb = (int)max_rows;                                                          \
+                if (tb < 1) tb = 1;                                                                                  \
+                blocks = tb;                                                                                         \
+                if (IDXB == 8) {                                                                                     \
+                    auto kern = k_point_grad_turns<IDXB, BK, 4, 4>;                                                  \
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); \
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, k, w.pg_part); \
+                } else {                                                                                             \
+                    auto kern = k_point_grad_turns<IDXB, BK, 8, 4>;                                                  \
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); \
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, k, w.pg_part); \
+                }                                                                                                    \
             }                                                                                                       \
             else if (big_u == 8) QD_PG(0, IDXB, BK, 8, true)                                                        \
             else if (big_u == 16) QD_PG(0, IDXB, BK, 16, true)                                                      \
             else QD_PG(0, IDXB, BK, 32, true)                                                                       \
         }
-        static int pg_shared = -1;                           // QD_PG_SHARED=0: one lane per column (A/B measurements)
-        if (pg_shared < 0) { const char* e = getenv("QD_PG_SHARED"); pg_shared = (e && e[0] == '0') ? 0 : 1; }
+        static int pg_turns = -1;                            // QD_PG_TURNS=0: one lane per column (A/B measurements)
+        if (pg_turns < 0) { const char* e = getenv("QD_PG_TURNS"); pg_turns = (e && e[0] == '0') ? 0 : 1; }
+        const int blocks_all = blocks_for(n, 256 * 4 * 2);
+        static int pg_bpc = 0;                               // resident blocks per CU of the turn-token kernel (QD_PG_BPC)
+        if (pg_bpc == 0) { const char* e = getenv("QD_PG_BPC"); pg_bpc = (e && atoi(e) > 0) ? atoi(e) : 2; }   // measured: k = 128: 63.4 (2) / 65.9 (3) us
         // A table above 64 KiB leaves ONE block per CU (4, 2 or 1 waves): the only way to keep enough bytes in flight
         // is more loads per lane -- each wave has a quarter of a SIMD's register file or more to itself.  U float4 of g
         // (+ their packed indices) per lane.  Measured (k = 128 / 256): U = 8: 66.6 / 121 us, 16: 68.5 / 110, 32: 79 / 119 --
