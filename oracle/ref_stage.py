@@ -14,7 +14,15 @@ gpurun-ignored, so it travels to the GPU box like the repo's own built .so files
 imports a package made of .pyc files alone ("sourceless" import) when the interpreter version
 matches, which it does: the GPU box runs this same image.
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call load(); the
+The same recipe stages the reference's TRAINING LOOP for the drop-in test
+(tests/test_hip_dropin_reference_loop.py): cnn_models/{__init__,conv_forward_model,help_fun}.py and
+helpers/functions.py under oracle/_ref/loop/.  One statement of help_fun.py cannot run on torch >= 0.5
+(`loss.data[0]` on a 0-dim tensor, cnn_models/help_fun.py:156,158 -- SURVEY.md section 4): it is replaced by
+`loss.item()` in the source text IN MEMORY before compiling; nothing else is touched and no source is
+written anywhere in the repository.  load_loop(pkg) imports that loop with `import quantization`
+resolving to `pkg` -- this repository's package or the staged reference package.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call load() / load_loop(); the
 product (quantized_distillation_amd/, quantization/, harness/) never does.
 """
 import hashlib
@@ -30,6 +38,13 @@ STAGE_DIR = os.path.join(_HERE, '_ref')
 PKG_DIR = os.path.join(STAGE_DIR, 'quantization')
 FILES = ('__init__.py', 'quant_functions.py', 'help_functions.py')
 _cached = None
+
+LOOP_DIR = os.path.join(STAGE_DIR, 'loop')
+# (path relative to the reference root, [(old, new), ...] applied to the source text before compiling)
+_ITEM_FIX = [('return loss.data[0], count_asked_teacher, count_total', 'return loss.item(), count_asked_teacher, count_total'),
+             ('        return loss.data[0]\n', '        return loss.item()\n')]
+LOOP_FILES = (('cnn_models/__init__.py', ()), ('cnn_models/conv_forward_model.py', ()),
+              ('cnn_models/help_fun.py', _ITEM_FIX), ('helpers/functions.py', ()))
 
 
 def stage(ref_root=REF_ROOT, force=False):
@@ -55,6 +70,79 @@ def stage(ref_root=REF_ROOT, force=False):
 
 def is_staged():
     return all(os.path.exists(os.path.join(PKG_DIR, f + 'c')) for f in FILES)
+
+
+def stage_loop(ref_root=REF_ROOT, force=False):
+    """Compile the reference's CNN training loop (train_model and what it imports) into oracle/_ref/loop/."""
+    import tempfile
+    if not all(os.path.exists(os.path.join(ref_root, rel)) for rel, _ in LOOP_FILES):
+        return LOOP_DIR if loop_is_staged() else None
+    for rel, fixes in LOOP_FILES:
+        src = os.path.join(ref_root, rel)
+        out = os.path.join(LOOP_DIR, rel + 'c')
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+            continue
+        if not fixes:
+            py_compile.compile(src, cfile=out, dfile='reference/' + rel, doraise=True)
+            continue
+        with open(src) as fh:
+            text = fh.read()
+        for old, new in fixes:
+            if old not in text:
+                raise RuntimeError('%s: the statement to fix is not there: %r' % (rel, old))
+            text = text.replace(old, new)
+        with tempfile.TemporaryDirectory() as tmp:              # the patched text never lands in the repository
+            tmp_src = os.path.join(tmp, os.path.basename(rel))
+            with open(tmp_src, 'w') as fh:
+                fh.write(text)
+            py_compile.compile(tmp_src, cfile=out, dfile='reference/' + rel + ' (loss.data[0] -> loss.item())', doraise=True)
+    return LOOP_DIR
+
+
+def loop_is_staged():
+    return all(os.path.exists(os.path.join(LOOP_DIR, rel + 'c')) for rel, _ in LOOP_FILES)
+
+
+def load_loop(quantization_pkg):
+    """The reference's cnn_models.conv_forward_model (train_model, ConvolForwardNet, ...) from the staged bytecode,
+    imported so that its `import quantization` / `import quantization.help_functions` resolve to `quantization_pkg`.
+    Every call returns a FRESH set of module objects (two loops bound to two quantizers can live side by side);
+    sys.modules is put back as it was.  None when nothing is staged and the reference is absent."""
+    if not loop_is_staged() and stage_loop() is None:
+        return None
+    names = ('cnn_models', 'cnn_models.conv_forward_model', 'cnn_models.help_fun', 'helpers', 'helpers.functions',
+             'quantization', 'quantization.quant_functions', 'quantization.help_functions')
+    saved = {k: sys.modules.pop(k) for k in names if k in sys.modules}
+    sys.modules['quantization'] = quantization_pkg
+    sys.modules['quantization.help_functions'] = quantization_pkg.help_functions
+    sys.modules['quantization.quant_functions'] = quantization_pkg.quant_functions
+    sys.path.insert(0, LOOP_DIR)
+    importlib.invalidate_caches()
+    # conv_forward_model.py imports scikit-learn at the top (:19-23) for functions train_model never calls; the GPU box
+    # has no scikit-learn, so empty stand-ins satisfy the import statements there
+    stubs = []
+    try:
+        import sklearn  # noqa: F401
+    except ImportError:
+        import types
+        for name in ('sklearn', 'sklearn.tree', 'sklearn.ensemble', 'sklearn.naive_bayes', 'sklearn.linear_model'):
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+                stubs.append(name)
+        for name in stubs[1:]:
+            setattr(sys.modules['sklearn'], name.split('.')[1], sys.modules[name])
+    try:
+        mod = importlib.import_module('cnn_models.conv_forward_model')
+        if not os.path.abspath(getattr(mod, '__file__', '') or '').startswith(LOOP_DIR):
+            raise ImportError('imported %r instead of the staged reference loop' % (mod,))
+    finally:
+        sys.path.remove(LOOP_DIR)
+        for k in names + tuple(stubs):
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+        importlib.invalidate_caches()
+    return mod
 
 
 def manifest():

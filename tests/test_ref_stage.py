@@ -55,3 +55,28 @@ def test_staged_reference_equals_oracle(n, bucket, s):
     want = onp.uniform_quantize(x.numpy(), s, bucket)
     assert np.array_equal(q.numpy(), want['q'])
     assert np.array_equal(sf.alpha.numpy().reshape(-1), want['alpha'].reshape(-1))
+
+
+@pytest.mark.skipif(not (ref_stage.loop_is_staged() or os.path.exists(ref_stage.REF_ROOT)), reason='reference loop not staged')
+def test_staged_reference_training_loop_runs_on_cpu_with_the_reference_quantizer():
+    """oracle/_ref/loop: the reference's train_model (bytecode, `loss.data[0]` -> `loss.item()`) imports with
+    `quantization` bound to the package handed to load_loop, leaves sys.modules as it found it, and trains."""
+    import contextlib
+    import io
+    import sys
+    import quantization as product
+    refq = ref_stage.load()
+    loop = ref_stage.load_loop(refq)
+    assert loop is not None and loop.quantization is refq
+    assert sys.modules['quantization'] is product and 'cnn_models' not in sys.modules
+    assert ref_stage.load_loop(refq) is not loop, 'every call gives fresh module objects'
+    torch.manual_seed(0)
+    model = loop.ConvolForwardNet(**loop.smallerModelSpec, useBatchNorm=True, useAffineTransformInBatchNorm=True)
+    g = torch.Generator().manual_seed(1)
+    batches = [(torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 10, (4,), generator=g)) for _ in range(2)]
+    if loop.USE_CUDA:
+        pytest.skip('a GPU is visible: tests/test_hip_dropin_reference_loop.py covers that case')
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, info = loop.train_model(model, batches, batches[:1], epochs_to_train=1, print_every=1, quantizeWeights=True,
+                                   numBits=4, bucket_size=256)
+    assert info['errorFlag'] is False and info['numEpochsTrained'] == 1 and len(info['lossSaved']) == 1
