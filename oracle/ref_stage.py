@@ -16,10 +16,12 @@ matches, which it does: the GPU box runs this same image.
 
 The same recipe stages the reference's TRAINING LOOP for the drop-in test
 (tests/test_hip_dropin_reference_loop.py): cnn_models/{__init__,conv_forward_model,help_fun}.py and
-helpers/functions.py under oracle/_ref/loop/.  One statement of help_fun.py cannot run on torch >= 0.5
-(`loss.data[0]` on a 0-dim tensor, cnn_models/help_fun.py:156,158 -- SURVEY.md section 4): it is replaced by
-`loss.item()` in the source text IN MEMORY before compiling; nothing else is touched and no source is
-written anywhere in the repository.  load_loop(pkg) imports that loop with `import quantization`
+helpers/functions.py under oracle/_ref/loop/.  Two statements cannot run on a current torch and are replaced in
+the source text IN MEMORY before compiling: `loss.data[0]` on a 0-dim tensor (cnn_models/help_fun.py:156,158 --
+SURVEY.md section 4) becomes `loss.item()`, and `optimizer.zero_grad()` in optimize_quantization_points
+(conv_forward_model.py:519), after which the loop writes `points.grad.data`, becomes
+`optimizer.zero_grad(set_to_none=False)` (torch >= 2.0 drops the gradients there by default).  Nothing else is
+touched and no source is written anywhere in the repository.  load_loop(pkg) imports that loop with `import quantization`
 resolving to `pkg` -- this repository's package or the staged reference package.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call load() / load_loop(); the
@@ -43,7 +45,10 @@ LOOP_DIR = os.path.join(STAGE_DIR, 'loop')
 # (path relative to the reference root, [(old, new), ...] applied to the source text before compiling)
 _ITEM_FIX = [('return loss.data[0], count_asked_teacher, count_total', 'return loss.item(), count_asked_teacher, count_total'),
              ('        return loss.data[0]\n', '        return loss.item()\n')]
-LOOP_FILES = (('cnn_models/__init__.py', ()), ('cnn_models/conv_forward_model.py', ()),
+# optimize_quantization_points writes `points.grad.data = ...` after `optimizer.zero_grad()` (conv_forward_model.py:519,545):
+# torch >= 2.0 sets gradients to None there by default
+_ZERO_GRAD_FIX = [('            optimizer.zero_grad()\n', '            optimizer.zero_grad(set_to_none=False)\n')]
+LOOP_FILES = (('cnn_models/__init__.py', ()), ('cnn_models/conv_forward_model.py', _ZERO_GRAD_FIX),
               ('cnn_models/help_fun.py', _ITEM_FIX), ('helpers/functions.py', ()))
 
 
@@ -96,7 +101,7 @@ def stage_loop(ref_root=REF_ROOT, force=False):
             tmp_src = os.path.join(tmp, os.path.basename(rel))
             with open(tmp_src, 'w') as fh:
                 fh.write(text)
-            py_compile.compile(tmp_src, cfile=out, dfile='reference/' + rel + ' (loss.data[0] -> loss.item())', doraise=True)
+            py_compile.compile(tmp_src, cfile=out, dfile='reference/' + rel + ' (+ torch-2 fix)', doraise=True)
     return LOOP_DIR
 
 
