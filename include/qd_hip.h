@@ -226,6 +226,18 @@ int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int 
                           const float* beta, float* y, void* stream);
 int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream);
 
+/* ---- order statistics for initialize_quantization_points (quantization/help_functions.py:140-154: the reference
+ * copies the scaled tensor to the host and calls np.percentile(a, linspace(0, 100, k)), which needs the two
+ * neighbouring order statistics of each of the k virtual indices).
+ * qd_order_stats_f32: out[t] (device, m floats) = the ranks[t]-th smallest element of x[0..n) (0-based; NaNs order
+ *   last, -0 before +0), found by a 12|10|10-bit radix SELECT: x is read three times and never sorted or modified.
+ *   ranks is a HOST array of m non-decreasing values in [0, n); 1 <= m <= QD_ORDER_STATS_MAX_RANKS; n < 2^32
+ *   (QD_ERR_UNSUPPORTED beyond either).  workspace: qd_order_stats_workspace_bytes(m) bytes of device memory. */
+#define QD_ORDER_STATS_MAX_RANKS 32
+size_t qd_order_stats_workspace_bytes(int m);
+int qd_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int m, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ def hipcc():
 def build_extension(force=False, verbose=False):
     srcs = [os.path.join(_lib.CSRC, 'qd_kernels.hip'), os.path.join(_lib.CSRC, 'qd_codec.hip'),
             os.path.join(_lib.CSRC, 'qd_multi_dq.hip'), os.path.join(_lib.CSRC, 'qd_abs.hip'),
-            os.path.join(_lib.CSRC, 'qd_multi_global.hip')]
+            os.path.join(_lib.CSRC, 'qd_multi_global.hip'), os.path.join(_lib.CSRC, 'qd_select.hip')]
     deps = srcs + [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h')]
     out = _lib.LIB_PATH
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):

@@ -97,13 +97,10 @@ def assign_bits_automatically(gradient_norms, inital_bits_to_assign, input_is_po
     return alloc
 
 
-def percentile_points_from_sorted(fetch, n, num_points):
-    """np.percentile(a, np.linspace(0, 100, num_points)) (method 'linear', float32 data) given only
-    random access to the SORTED data: `fetch(int64 index array) -> float32 values`.  Reproduces
-    numpy's arithmetic exactly (virtual index (n-1)*q with q = p/float32(100); float32 difference
-    of the two neighbours; float64 lerp with the t >= 0.5 branch of numpy's _lerp), so the result is
-    bit-identical to the reference's host-side call (ref: help_functions.py:150) while only
-    2*num_points values ever leave the device."""
+def percentile_ranks(n, num_points):
+    """The two neighbouring 0-based ranks and the interpolation weight of each of the `num_points` percentiles
+    np.linspace(0, 100, num_points) of n values, with numpy's arithmetic (method 'linear': virtual index
+    (n-1)*q with q = p/float32(100))."""
     quant = np.true_divide(np.linspace(0, 100, num=num_points), np.float32(100))
     virtual = (n - 1) * quant
     lower = np.floor(virtual)
@@ -112,12 +109,60 @@ def percentile_points_from_sorted(fetch, n, num_points):
     lower[at_end] = n - 1
     upper[at_end] = n - 1
     gamma = virtual - np.floor(virtual)
-    a = np.asarray(fetch(lower.astype(np.int64)), dtype=np.float32)
-    b = np.asarray(fetch(upper.astype(np.int64)), dtype=np.float32)
+    return lower.astype(np.int64), upper.astype(np.int64), gamma
+
+
+def percentile_lerp(a, b, gamma):
+    """numpy's _lerp on float32 neighbours: float32 difference, float64 lerp, the t >= 0.5 branch taken from b."""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
     diff = np.subtract(b, a)
     result = np.add(a, diff * gamma)
     np.subtract(b, diff * (1 - gamma), out=result, where=gamma >= 0.5)
     return result
+
+
+def percentile_points_from_sorted(fetch, n, num_points):
+    """np.percentile(a, np.linspace(0, 100, num_points)) (method 'linear', float32 data) given only
+    random access to the SORTED data: `fetch(int64 index array) -> float32 values`.  Reproduces
+    numpy's arithmetic exactly, so the result is bit-identical to the reference's host-side call
+    (ref: help_functions.py:150) while only 2*num_points values ever leave the device."""
+    lower, upper, gamma = percentile_ranks(n, num_points)
+    return percentile_lerp(fetch(lower), fetch(upper), gamma)
+
+
+ORDER_STATS_MAX_PASSES = 2       # above 2 * QD_ORDER_STATS_MAX_RANKS distinct ranks the device sort is cheaper than selecting
+
+
+def order_statistics(values, ranks):
+    """values[...] sorted ascending, at the (numpy int64, any order, repeats allowed) 0-based `ranks` -- as a float32
+    numpy array, without sorting: a 12|10|10-bit radix select on the device (qd_order_stats_f32, csrc/qd_select.hip)
+    reads `values` three times per 32 distinct ranks and only the selected values leave the device.  More than
+    2 * 32 distinct ranks (num_points > 32): one device sort and a gather instead."""
+    from .. import _lib
+    flat = values.reshape(-1)
+    if flat.dtype != torch.float32 or not flat.is_cuda:
+        raise TypeError('order_statistics needs a float32 tensor on the GPU, got %s on %s' % (flat.dtype, flat.device))
+    ranks = np.asarray(ranks, dtype=np.int64)
+    n = flat.numel()
+    if ranks.size and (ranks.min() < 0 or ranks.max() >= n):
+        raise IndexError('rank out of range for %d elements' % n)
+    distinct, inverse = np.unique(ranks, return_inverse=True)
+    lib = _lib.load()
+    chunk = 32                                                          # QD_ORDER_STATS_MAX_RANKS
+    if distinct.size > ORDER_STATS_MAX_PASSES * chunk or n >= 2 ** 32:
+        ordered = torch.sort(flat)[0]
+        return ordered[torch.from_numpy(ranks).to(flat.device)].cpu().numpy()
+    flat = flat.contiguous()
+    out = torch.empty(distinct.size, dtype=torch.float32, device=flat.device)
+    with torch.cuda.device(flat.device):
+        ws_bytes = lib.qd_order_stats_workspace_bytes(min(chunk, int(distinct.size)))
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=flat.device)
+        for start in range(0, distinct.size, chunk):
+            part = np.ascontiguousarray(distinct[start:start + chunk])
+            _lib.check(lib.qd_order_stats_f32(flat.data_ptr(), n, part.ctypes.data, int(part.size),
+                                              out.data_ptr() + 4 * start, workspace.data_ptr(), ws_bytes, _lib.stream_ptr()))
+    return out.cpu().numpy()[inverse.reshape(ranks.shape)]
 
 
 def initialize_quantization_points(tensor, scaling_function, num_points):
@@ -125,17 +170,15 @@ def initialize_quantization_points(tensor, scaling_function, num_points):
     percentiles of the scaled tensor.  ref: help_functions.py:140-154.
 
     The reference copies the whole scaled tensor to the host and runs np.percentile there.  Here
-    the scaling (K2) and the sort run on the device and only the 2*num_points order statistics
-    the interpolation needs are copied back; the interpolation itself is numpy's, so the result
-    is bit-identical (tests/golden/misc.npz)."""
+    the scaling (K2) runs on the device, the 2*num_points order statistics the interpolation needs
+    are SELECTED on the device (order_statistics: three reads of the tensor, no sort) and only they
+    are copied back; the interpolation itself is numpy's, so the result is bit-identical
+    (tests/golden/misc.npz)."""
     n = tensor.numel()
     scaled = scaling_function.scale_down(tensor).view(-1)[0:scaling_function.original_tensor_length]
-    ordered = torch.sort(scaled)[0]
-
-    def fetch(index):
-        return ordered[torch.from_numpy(index).to(ordered.device)].cpu().numpy()
-
-    values = percentile_points_from_sorted(fetch, n, num_points)
+    lower, upper, gamma = percentile_ranks(n, num_points)
+    found = order_statistics(scaled, np.concatenate([lower, upper]))
+    values = percentile_lerp(found[:num_points], found[num_points:], gamma)
     return torch.from_numpy(values).type_as(tensor).to(tensor.device)
 
 
