@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_hist_u8(const uint8_t* idx, int64_t n, 
 // quantizer) is counted symbol by symbol instead.  Symbols in [k, 16) are counted and dropped at the end.
 // Blocks are 1024 lanes: every block ends with k global atomics on one cache line, so the grid is ONE block per CU -- 16
 // waves, four per SIMD -- instead of many small ones.
-template <int U>
+template <int U, bool PF>
 __global__ __launch_bounds__(1024) void k_hist_reg16(const uint8_t* idx, int64_t n, int k, unsigned long long* hist) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     __shared__ unsigned long long wsum[16][16];
@@ -314,18 +314,64 @@ __global__ __launch_bounds__(1024) void k_hist_reg16(const uint8_t* idx, int64_t
     int64_t done = 0;
     if ((((uintptr_t)idx) & 15) == 0) {
         const int64_t n16 = n >> 4;
-        int64_t i = tid;
-        for (; i + (int64_t)(U - 1) * nth < n16; i += (int64_t)U * nth) {
-            u4 w[U];
+        if (PF) {
+            // Software pipeline.  All waves of the resident grid start together, so without it the whole chip alternates
+            // between a load phase (VALU idle) and a counting phase (HBM idle): time = sum of the two, not their maximum.
+            // The grid-uniform number of whole rounds (every lane U valid loads) runs double-buffered -- the loads of round
+            // r + 1 are in flight while round r is counted -- with always-issued loads (the round index clamped: the last
+            // round is fetched twice, from L2) so that no load sits behind a branch; the remainder is ONE more batch with
+            // per-lane validity.
+            const int64_t per_round = (int64_t)U * nth;
+            const int64_t rounds = n16 / per_round;
+            const u4* base = (const u4*)idx + tid;
+            auto fetch = [&](u4 (&w)[U], int64_t r) {
+                const int64_t rr = r < rounds ? r : rounds - 1;
 #pragma unroll
-            for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load((const u4*)idx + i + (int64_t)u * nth);
-            __builtin_amdgcn_sched_barrier(0);                      // keep the U loads in flight together
-            count_loads(w, U);
-        }
-        for (; i < n16; i += nth) {
-            u4 w[U];
-            w[0] = __builtin_nontemporal_load((const u4*)idx + i);
-            count_loads(w, 1);
+                for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(base + rr * per_round + (int64_t)u * nth);
+            };
+            if (rounds > 0) {
+                u4 a[U], b[U];
+                fetch(a, 0);
+                for (int64_t r = 0; r < rounds; r += 2) {
+                    fetch(b, r + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    count_loads(a, U);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch(a, r + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r + 1 < rounds) count_loads(b, U);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            {
+                const int64_t i0 = rounds * per_round + tid;
+                const int64_t left = n16 - i0;                     // may be <= 0
+                const int nvalid = left <= 0 ? 0 : (int)((left + nth - 1) / nth < U ? (left + nth - 1) / nth : U);
+                if (__any(nvalid > 0)) {
+                    u4 w[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int64_t j = i0 + (int64_t)u * nth;
+                        w[u] = __builtin_nontemporal_load((const u4*)idx + (j < n16 ? j : n16 - 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    count_loads(w, nvalid);
+                }
+            }
+        } else {
+            int64_t i = tid;
+            for (; i + (int64_t)(U - 1) * nth < n16; i += (int64_t)U * nth) {
+                u4 w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load((const u4*)idx + i + (int64_t)u * nth);
+                __builtin_amdgcn_sched_barrier(0);                      // keep the U loads in flight together
+                count_loads(w, U);
+            }
+            for (; i < n16; i += nth) {
+                u4 w[U];
+                w[0] = __builtin_nontemporal_load((const u4*)idx + i);
+                count_loads(w, 1);
+            }
         }
         done = n16 << 4;
     }
@@ -344,6 +390,68 @@ __global__ __launch_bounds__(1024) void k_hist_reg16(const uint8_t* idx, int64_t
         unsigned long long t = 0;
         for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) t += wsum[w2][threadIdx.x];
         if (t) atomicAdd(&hist[threadIdx.x], t);
+    }
+}
+
+// histogram of uint8 symbols, any k <= 256, with INTEGER LDS atomics (ds_add_u32 without return) on a [k + 1][32]
+// table shared by the block: column = lane mod 32, so the 32 lanes the LDS serves per cycle hit 32 different banks
+// whatever their symbols are, and two lanes (or waves) that meet on one counter are resolved by the LDS itself -- no
+// read-modify-write in registers, no duplicate merging, 3 VALU operations per symbol, 4.1-33 KiB of LDS per block.
+template <int U>
+__global__ __launch_bounds__(256) void k_hist_atomic(const uint8_t* idx, int64_t n, int k, unsigned long long* hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hist_lds[];
+    uint32_t* cnt = (uint32_t*)hist_lds;                                   // [k + 1][32], row k = dummy (symbols >= k)
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * 256;
+    for (int j = threadIdx.x; j < (k + 1) * 32; j += 256) cnt[j] = 0;
+    __syncthreads();
+    uint32_t* col = cnt + (threadIdx.x & 31);
+    const uint32_t kk = (uint32_t)k;
+    auto bump = [&](uint32_t sy) { __hip_atomic_fetch_add(col + (sy < kk ? sy : kk) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto bump_word = [&](uint32_t v) { bump(v & 255u); bump((v >> 8) & 255u); bump((v >> 16) & 255u); bump(v >> 24); };
+    int64_t done = 0;
+    if ((((uintptr_t)idx) & 15) == 0) {
+        const int64_t n16 = n >> 4;
+        const int64_t per_round = (int64_t)U * nth;
+        const int64_t rounds = n16 / per_round;
+        const u4* base = (const u4*)idx + tid;
+        auto fetch = [&](u4 (&w)[U], int64_t r) {
+            const int64_t rr = r < rounds ? r : rounds - 1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(base + rr * per_round + (int64_t)u * nth);
+        };
+        auto count = [&](const u4 (&w)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { bump_word(w[u].x); bump_word(w[u].y); bump_word(w[u].z); bump_word(w[u].w); }
+        };
+        if (rounds > 0) {                                    // double-buffered whole rounds, as k_hist_reg16
+            u4 a[U], b[U];
+            fetch(a, 0);
+            for (int64_t r = 0; r < rounds; r += 2) {
+                fetch(b, r + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                count(a);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(a, r + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (r + 1 < rounds) count(b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        for (int64_t i = rounds * per_round + tid; i < n16; i += nth) {
+            const u4 w = __builtin_nontemporal_load((const u4*)idx + i);
+            bump_word(w.x); bump_word(w.y); bump_word(w.z); bump_word(w.w);
+        }
+        done = n16 << 4;
+    }
+    for (int64_t i = done + tid; i < n; i += nth) bump(idx[i]);
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 256) {
+        unsigned long long total = 0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) total += cnt[j * 32 + ((c + j) & 31)];
+        if (total) atomicAdd(&hist[j], total);
     }
 }
 
@@ -444,9 +552,30 @@ int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* 
         static int u_sel = 0;
         if (u_sel == 0) { const char* e = getenv("QD_HIST_U"); u_sel = (e && atoi(e) > 0) ? atoi(e) : 8; }
         const int cap = cus < 256 ? cus : 256;
-        if (u_sel == 16) hipLaunchKernelGGL((k_hist_reg16<16>), dim3(blocks_for(n, 1024 * 16 * 16, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
-        else if (u_sel == 4) hipLaunchKernelGGL((k_hist_reg16<4>), dim3(blocks_for(n, 1024 * 16 * 4, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
-        else hipLaunchKernelGGL((k_hist_reg16<8>), dim3(blocks_for(n, 1024 * 16 * 8, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
+        static int pf_sel = -1;
+        if (pf_sel < 0) { const char* e = getenv("QD_HIST_PF"); pf_sel = e ? atoi(e) : 0; }      // software-pipelined rounds (A/B)
+        if (pf_sel) {
+            if (u_sel == 2) hipLaunchKernelGGL((k_hist_reg16<2, true>), dim3(blocks_for(n, 1024 * 16 * 2, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
+            else if (u_sel == 4) hipLaunchKernelGGL((k_hist_reg16<4, true>), dim3(blocks_for(n, 1024 * 16 * 4, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
+            else hipLaunchKernelGGL((k_hist_reg16<8, true>), dim3(blocks_for(n, 1024 * 16 * 8, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
+            return (int)hipGetLastError();
+        }
+        if (u_sel == 16) hipLaunchKernelGGL((k_hist_reg16<16, false>), dim3(blocks_for(n, 1024 * 16 * 16, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
+        else if (u_sel == 4) hipLaunchKernelGGL((k_hist_reg16<4, false>), dim3(blocks_for(n, 1024 * 16 * 4, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
+        else hipLaunchKernelGGL((k_hist_reg16<8, false>), dim3(blocks_for(n, 1024 * 16 * 8, cap)), dim3(1024), 0, st, idx, n, k, (unsigned long long*)hist);
+        return (int)hipGetLastError();
+    }
+    static int at_sel = -1;
+    if (at_sel < 0) { const char* e = getenv("QD_HIST_ATOMIC"); at_sel = e ? atoi(e) : 0; }   // LDS-atomic table, blocks per CU (A/B)
+    if (at_sel > 0) {
+        // a uint32 counter holds what ONE block counts in one launch: slices of at most blocks * 2^31 symbols
+        const size_t lds = (size_t)(k + 1) * 32 * sizeof(uint32_t);
+        const int blocks = blocks_for(n, 256 * 16 * 4, cus * at_sel);
+        const int64_t slice = (int64_t)blocks << 31;
+        for (int64_t off = 0; off < n; off += slice) {
+            const int64_t len = n - off < slice ? n - off : slice;
+            hipLaunchKernelGGL((k_hist_atomic<4>), dim3(blocks), dim3(256), lds, st, idx + off, len, k, (unsigned long long*)hist);
+        }
         return (int)hipGetLastError();
     }
     const size_t lds_bytes = (size_t)(k + 1) * 256 * (k <= 64 ? sizeof(uint32_t) : sizeof(uint16_t));

@@ -665,7 +665,7 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
 // and finally every lane streams its float4s from LDS to HBM, coalesced.  (The first version transformed the register
 // copy and picked (alpha, beta) per element from the two candidate buckets: 48 VALU instructions per element against
 // 32 in the vector kernel, VALU-bound at 107-138 us for 64 Mi elements.)
-template <int MODE, int VMAX>
+template <int MODE, int VMAX, bool PF = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 6)))
 void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
     __shared__ PointTable Ts;
@@ -693,11 +693,36 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
     const int64_t wave = uniform_wave_index();
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 
+    // PF: the chunk a wave works on next is fetched into registers while the current one goes through its LDS phases
+    // (the loads of a wave otherwise only overlap with OTHER waves' phases); always issued, the chunk index clamped.
+    f4 vpf[PF ? VMAX : 1];
+    auto fetch_chunk = [&](int64_t c) {
+        const f4* src = (const f4*)(p.x + c * m * p.row);
+#pragma unroll
+        for (int j = 0; j < (PF ? VMAX : 0); ++j) {
+            const int f = lane + 64 * j;
+            vpf[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+        }
+    };
+    if (PF && wave < nchunks) fetch_chunk(wave);
     for (int64_t c = wave; c < nchunks; c += nwaves) {
         const int64_t b0 = c * m;
         const int64_t e0 = b0 * p.row;
         const f4* src = (const f4*)(p.x + e0);
-        {
+        if (PF) {
+#pragma unroll
+            for (int j = 0; j < (PF ? VMAX : 0); ++j) {
+                const int f = lane + 64 * j;
+                if (j < nj && f < nf) {
+                    f4 t = vpf[j];
+                    if (!prescaled && prep_on) t = prep4(t, pp);
+                    ((f4*)vals)[f] = t;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_chunk(c + nwaves < nchunks ? c + nwaves : c);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
             f4 v[VMAX];
 #pragma unroll
             for (int j = 0; j < VMAX; ++j) {           // always-issued loads with a clamped address, as above
@@ -2067,7 +2092,22 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         if (nchunks > 0) {
             const size_t lds = (size_t)2 * (kChunkV * 128) * sizeof(float2);              // two waves: the staged chunk
             const int blocks = blocks_for(nchunks, 2) + 1;
-            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
+            static int pf_sel = -1;
+            if (pf_sel < 0) { const char* e = getenv("QD_CHUNK_PF"); pf_sel = e ? atoi(e) : 0; }   // prefetching variant (A/B)
+            if (MODE == MODE_QDQ && pf_sel) {
+                // persistent grid, pf_sel blocks per CU: a wave works through several chunks, fetching the next one early
+                static int cus = 0;
+                if (cus == 0) {
+                    int dev = 0;
+                    if (hipGetDevice(&dev) != hipSuccess ||
+                        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                        cus = 256;
+                }
+                const int64_t cap = (int64_t)cus * pf_sel;
+                const int pblocks = (int)(blocks - 1 < cap ? blocks - 1 : cap) + 1;
+                hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV, MODE == MODE_QDQ>), dim3(pblocks), dim3(128), lds, st, p, m, nchunks);
+            } else
+                hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
             return check_launch();
         }
     }

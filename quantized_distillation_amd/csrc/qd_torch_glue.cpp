@@ -165,6 +165,161 @@ PyObject* glue_uniform(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     END_HANDLE_TH_ERRORS
 }
 
+// ---- the common case of uniformQuantization as ONE native call ---------------------------------------------------
+// uniform_common(tensor, s, bucket_size | None) -> (q, ScalingFunction) | None
+//
+// The reference's training loops call uniformQuantization(p.data, s, bucket_size=B) once per parameter tensor per step
+// (cnn_models/conv_forward_model.py:235-247) and drop the ScalingFunction.  For exactly that configuration -- linear
+// scaling, deterministic rounding, no clamp, no mean, out of place, contiguous fp32 device tensor -- this entry point
+// does everything the Python function would do: allocate q, take alpha/beta from a per-(device, stream) SLAB (a bump
+// pointer instead of a second trip through the caching allocator: only the slab and an offset are recorded, the views
+// are made when sf.alpha / sf.beta are read), launch qd_uniform_f32, and build the ScalingFunction instance directly
+// (its class-level defaults cover every field the call does not set).  Anything else returns None and the caller takes
+// the general path, which also raises the reference's exceptions for bad arguments.
+PyTypeObject* g_sf_type = nullptr;
+PyObject *s_bucket_size, *s_n, *s_ab, *s_ab_slab, *s_ab_off, *s_arg_source, *s_arg_version, *s_mean_tensor, *s_zero;
+
+struct Slab {
+    int device;
+    void* stream;
+    at::Tensor t;      // [kSlabFloats] fp32
+    PyObject* py;      // its Python wrapper (one reference held here; every ScalingFunction carved from it holds one too)
+    int64_t used;
+};
+std::vector<Slab> g_slabs;
+constexpr int64_t kSlabFloats = 1 << 18;          // 1 MiB; requests above a quarter of it get their own allocation
+
+PyObject* glue_register(PyObject*, PyObject* type) {
+    if (!PyType_Check(type)) {
+        PyErr_SetString(PyExc_TypeError, "register() takes the ScalingFunction class");
+        return nullptr;
+    }
+    Py_INCREF(type);
+    Py_XDECREF(reinterpret_cast<PyObject*>(g_sf_type));
+    g_sf_type = reinterpret_cast<PyTypeObject*>(type);
+    if (!s_n) {
+        s_bucket_size = PyUnicode_InternFromString("bucket_size");
+        s_n = PyUnicode_InternFromString("_n");
+        s_ab = PyUnicode_InternFromString("_ab");
+        s_ab_slab = PyUnicode_InternFromString("_ab_slab");
+        s_ab_off = PyUnicode_InternFromString("_ab_off");
+        s_arg_source = PyUnicode_InternFromString("_arg_source");
+        s_arg_version = PyUnicode_InternFromString("_arg_version");
+        s_mean_tensor = PyUnicode_InternFromString("mean_tensor");
+        s_zero = PyLong_FromLong(0);
+    }
+    Py_RETURN_NONE;
+}
+
+PyObject* glue_uniform_common(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
+    HANDLE_TH_ERRORS
+    if (nargs != 3 || !g_sf_type || !THPVariable_Check(args[0]) || !PyLong_CheckExact(args[1])) Py_RETURN_NONE;
+    const at::Tensor& x = THPVariable_Unpack(args[0]);
+    if (!x.is_cuda() || x.scalar_type() != at::kFloat || !x.is_contiguous() || x.is_inference()) Py_RETURN_NONE;
+    const long levels = PyLong_AsLong(args[1]);
+    long long bucket = 0;
+    if (args[2] != Py_None) {
+        if (!PyLong_CheckExact(args[2])) Py_RETURN_NONE;
+        bucket = PyLong_AsLongLong(args[2]);
+        if (bucket <= 0) bucket = -1;
+    }
+    if (PyErr_Occurred()) {                               // out-of-range integers: the general path reports them
+        PyErr_Clear();
+        Py_RETURN_NONE;
+    }
+    const int64_t n = x.numel();
+    if (levels < 2 || levels > 0x7fffffffL || bucket < 0 || n == 0) Py_RETURN_NONE;
+
+    const c10::Device dev = x.device();
+    c10::hip::OptionalHIPGuard guard;
+    if (dev.index() != c10::hip::current_device()) guard.set_index(dev.index());
+    void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    const int64_t nb = num_buckets(n, bucket);
+    at::Tensor q(at::detail::empty_cuda(x.sizes(), at::kFloat, dev, c10::nullopt));
+
+    // alpha / beta: 2 * nb floats from the slab of this (device, stream), 16-byte granules
+    const int64_t need = (2 * nb + 3) & ~int64_t(3);
+    float* abp = nullptr;
+    PyObject* ab_owner = nullptr;                          // new reference: the slab's wrapper or a dedicated [2, nb, 1] tensor
+    int64_t ab_off = -1;
+    if (need <= kSlabFloats / 4) {
+        Slab* sl = nullptr;
+        for (auto& c : g_slabs)
+            if (c.device == dev.index() && c.stream == stream) { sl = &c; break; }
+        if (!sl) {
+            g_slabs.push_back({static_cast<int>(dev.index()), stream, at::Tensor(), nullptr, kSlabFloats});
+            sl = &g_slabs.back();
+        }
+        if (sl->used + need > kSlabFloats) {               // a fresh slab; the old one lives as long as something carved from it
+            at::Tensor t = empty_f32({kSlabFloats}, dev);
+            PyObject* py = THPVariable_Wrap(t);
+            if (!py) return nullptr;
+            Py_XDECREF(sl->py);
+            sl->t = std::move(t);
+            sl->py = py;
+            sl->used = 0;
+        }
+        ab_off = sl->used;
+        sl->used += need;
+        abp = sl->t.data_ptr<float>() + ab_off;
+        ab_owner = sl->py;
+        Py_INCREF(ab_owner);
+    } else {
+        at::Tensor ab = bucket > 0 ? empty_f32({2, nb, 1}, dev) : empty_f32({2, 1}, dev);
+        abp = ab.data_ptr<float>();
+        ab_owner = THPVariable_Wrap(ab);
+        if (!ab_owner) return nullptr;
+    }
+    struct Drop { PyObject* o; ~Drop() { Py_XDECREF(o); } } drop_owner{ab_owner};
+
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    if (nb == 1) ws = workspace_for(dev, stream, &ws_bytes);
+    check_rc(qd_uniform_f32(x.data_ptr<float>(), q.data_ptr<float>(), n, bucket, static_cast<int>(levels), abp, abp + nb, nullptr,
+                            nullptr, 0, 0.0f, 0, 0, ws, ws_bytes, stream));
+
+    // ScalingFunction instance without running __init__ (the checks it makes are the ones made above)
+    PyObject* sf = g_sf_type->tp_alloc(g_sf_type, 0);
+    if (!sf) return nullptr;
+    Drop drop_sf{sf};
+    PyObject** dp = _PyObject_GetDictPtr(sf);
+    if (!dp) {
+        PyErr_SetString(PyExc_TypeError, "ScalingFunction instances must have a __dict__");
+        return nullptr;
+    }
+    PyObject* d = *dp;
+    if (!d) {
+        d = PyDict_New();
+        if (!d) return nullptr;
+        *dp = d;
+    }
+    PyObject* n_obj = PyLong_FromLongLong(n);
+    PyObject* ver_obj = PyLong_FromLongLong(static_cast<long long>(x._version()));
+    Drop drop_n{n_obj}, drop_ver{ver_obj};
+    if (!n_obj || !ver_obj) return nullptr;
+    int rc = PyDict_SetItem(d, s_bucket_size, args[2]) | PyDict_SetItem(d, s_n, n_obj) |
+             PyDict_SetItem(d, s_arg_source, args[0]) | PyDict_SetItem(d, s_arg_version, ver_obj) |
+             PyDict_SetItem(d, s_mean_tensor, s_zero);                               // ref: :70
+    if (ab_off >= 0) {
+        PyObject* off_obj = PyLong_FromLongLong(ab_off);
+        Drop drop_off{off_obj};
+        if (!off_obj) return nullptr;
+        rc |= PyDict_SetItem(d, s_ab_slab, ab_owner) | PyDict_SetItem(d, s_ab_off, off_obj);
+    } else {
+        rc |= PyDict_SetItem(d, s_ab, ab_owner);
+    }
+    if (rc) return nullptr;
+    PyObject* qo = THPVariable_Wrap(q);
+    if (!qo) return nullptr;
+    PyObject* out = PyTuple_New(2);
+    if (!out) { Py_DECREF(qo); return nullptr; }
+    PyTuple_SET_ITEM(out, 0, qo);
+    drop_sf.o = nullptr;                                    // the tuple owns it now
+    PyTuple_SET_ITEM(out, 1, sf);
+    return out;
+    END_HANDLE_TH_ERRORS
+}
+
 // nearest(x, prescaled, points, assign_mode, n, bucket, alpha, beta, mean | None, clamp, max_element, idx_bytes)
 //   -> (q [n], idx [n] int64 | uint8).  alpha/beta are outputs when prescaled == 0, inputs otherwise.
 //   One qd_nearest_point_f32 launch.
@@ -310,6 +465,9 @@ PyObject* glue_host_cost_probe(PyObject*, PyObject* const* args, Py_ssize_t narg
 PyMethodDef methods[] = {
     {"uniform", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_uniform)), METH_FASTCALL,
      "uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place) -> (q, ab, mean, n, x_read)"},
+    {"uniform_common", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_uniform_common)), METH_FASTCALL,
+     "uniform_common(tensor, s, bucket_size | None) -> (q, ScalingFunction) for the training loops' configuration, None otherwise"},
+    {"register", glue_register, METH_O, "register(ScalingFunction): the class uniform_common instantiates"},
     {"nearest", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_nearest)), METH_FASTCALL,
      "nearest(x, prescaled, points, assign_mode, n, bucket, alpha, beta, mean, clamp, max_element, idx_bytes) -> (q, idx)"},
     {"point_grad", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_point_grad)), METH_FASTCALL,

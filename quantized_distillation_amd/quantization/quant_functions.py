@@ -65,12 +65,18 @@ class ScalingFunction(object):
     # ScalingFunction per parameter tensor per step (ref: conv_forward_model.py:235-247), so its construction
     # is on the host-side critical path of the drop-in.
     tol_diff_zero = 1e-10
+    type_scaling = 'linear'        # what the native common-case entry point (glue.uniform_common) leaves unset: it builds the
+    max_element = False            # instance without running __init__, for exactly this configuration
+    subtract_mean = False
+    modify_in_place = True         # as the reference's uniformQuantization sets it, :166-167
     mean_tensor = None
     _shape = None
     norm_scaling = None
     tensor_sign = None
     _n = None
     _ab = None                     # [2, nb, 1] / [2, 1]: alpha and beta in one allocation, split on first access
+    _ab_slab = None                # ... or 2 * nb floats at offset _ab_off of a slab shared by many calls (glue.uniform_common)
+    _ab_off = None
     _alpha = None
     _beta = None
     _idx_min_rows = None
@@ -97,10 +103,21 @@ class ScalingFunction(object):
         self.modify_in_place = modify_in_place
 
     # ------------------------------------------------------------------ lazily materialised fields
+    def _split_ab(self):
+        ab = self._ab
+        if ab is None:
+            if self._ab_slab is None:
+                return
+            nb = _geometry(self._n, self.bucket_size)[0]
+            ab = self._ab_slab[self._ab_off:self._ab_off + 2 * nb]
+            ab = ab.view(2, 1) if self.bucket_size is None else ab.view(2, nb, 1)
+            self._ab = ab
+        self._alpha, self._beta = ab.unbind(0)
+
     @property
     def alpha(self):
-        if self._alpha is None and self._ab is not None:
-            self._alpha, self._beta = self._ab.unbind(0)
+        if self._alpha is None:
+            self._split_ab()
         return self._alpha
 
     @alpha.setter
@@ -109,8 +126,8 @@ class ScalingFunction(object):
 
     @property
     def beta(self):
-        if self._beta is None and self._ab is not None:
-            self._alpha, self._beta = self._ab.unbind(0)
+        if self._beta is None:
+            self._split_ab()
         return self._beta
 
     @beta.setter
@@ -188,7 +205,7 @@ class ScalingFunction(object):
             ab = torch.empty(2, 1, dtype=torch.float32, device=device)
         else:
             ab = torch.empty(2, nb, 1, dtype=torch.float32, device=device)
-        self._ab, self._alpha, self._beta = ab, None, None
+        self._ab, self._alpha, self._beta, self._ab_slab = ab, None, None, None
         return ab
 
     def _note_arg_source(self, tensor, overwritten):
@@ -315,6 +332,7 @@ class ScalingFunction(object):
 
 
 _glue_uniform = None
+_glue_uniform_common = None
 _new_object = object.__new__
 
 
@@ -334,9 +352,18 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     The common configuration of the training loops (linear scaling, no clamp, no mean, out of
     place; ref: conv_forward_model.py:216-221) takes a path with the argument checks inlined --
     this function is called once per parameter tensor per step."""
-    global _glue_uniform
+    global _glue_uniform, _glue_uniform_common
     if _glue_uniform is None:
-        _glue_uniform = _lib.glue().uniform
+        g = _lib.glue()
+        g.register(ScalingFunction)
+        _glue_uniform, _glue_uniform_common = g.uniform, g.uniform_common
+    if (type_of_scaling == 'linear' and max_element is False and not modify_in_place and not stochastic_rounding
+            and not subtract_mean):
+        # the configuration of the training loops (ref: conv_forward_model.py:216-221, 235-247): one native call that
+        # returns (q, ScalingFunction) -- or None when an argument needs the checks / conversions of the general path
+        done = _glue_uniform_common(tensor, s, bucket_size)
+        if done is not None:
+            return done
     if (type_of_scaling == 'linear' and max_element is False and not modify_in_place
             and (bucket_size is None or (type(bucket_size) is int and bucket_size > 0))
             and type(s) is int and s >= 2):

@@ -152,6 +152,24 @@ def test_uniform_random_sweep_vs_c_oracle(bucket):
             assert np.array_equal(host(sf.idx_max_rows).reshape(-1), r['imax']), (n, s, bucket)
 
 
+@pytest.mark.parametrize('bucket', [33, 50, 7, 250, 511, 100, 1000, 513])
+def test_uniform_chunk_kernels_many_chunks_per_wave(bucket):
+    """16.7 M elements: more chunks than a resident grid of the chunk kernels holds, so a wave that works through several
+    chunks (persistent / prefetching launch shapes) is exercised; stochastic branch too (the draw is indexed by element)."""
+    n = (1 << 24) + 12345
+    x = (torch.randn(n, generator=torch.Generator().manual_seed(bucket)) * 0.3).numpy()
+    q, sf = quantization.uniformQuantization(dev(x), 16, bucket_size=bucket)
+    r = oc.uniform_quantize(x, 16, bucket)
+    assert np.array_equal(host(q), r['q'])
+    assert np.array_equal(host(sf.alpha).reshape(-1), r['alpha']) and np.array_equal(host(sf.beta).reshape(-1), r['beta'])
+    seed = quantization.quant_functions.next_stochastic_seed(peek=True)
+    qs, _ = quantization.uniformQuantization(dev(x), 16, bucket_size=bucket, stochastic_rounding=True)
+    rand = np.zeros(onp.bucket_geometry(n, bucket)[2], np.float32)
+    rand[:n] = onp.philox4x32_7_uniform(seed, n)
+    want = onp.uniform_quantize_stochastic(x, 16, rand, bucket)
+    assert np.array_equal(host(qs), want['q'])
+
+
 def test_uniform_big_checksums_from_reference(golden_big):
     for c in golden_big:
         if c['op'] != 'uniform':

@@ -46,7 +46,7 @@ for i in range(600):
     quantization.uniformQuantization(xs[i % R], 16, bucket_size=256)
 torch.cuda.synchronize()
 if 'chunk' in what:
-    for b in (33, 50, 250, 7, 511, 513, 1001, 100, 36, 1000, 12, 2000):
+    for b in [int(v) for v in os.environ.get('TUNE_BUCKETS', '33,50,250,7,511,513,1001,100,36,1000,12,2000').split(',')]:
         timeit('K1 uniform 4-bit bucket %d' % b,
                lambda i, b=b: live.__setitem__(i % R, quantization.uniformQuantization(xs[i % R], 16, bucket_size=b)[0]), 8, iters=12)
 if 'k6' in what:
@@ -61,7 +61,7 @@ if 'k6' in what:
         del fns
     del gs
 if 'hist' in what:
-    for k in (4, 16, 64, 256):
+    for k in [int(v) for v in os.environ.get('TUNE_HIST_K', '4,16,64,256').split(',')]:
         lev8 = [torch.randint(0, k, (N,), dtype=torch.uint8, device=dev) for _ in range(R)]
         timeit('HST histogram of uint8 levels, k=%d' % k, lambda i: codec.histogram_u8(lev8[i % R], k), 1)
         # levels as the quantizer produces them (bell-shaped: most symbols in a few bins)
