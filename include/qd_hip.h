@@ -218,13 +218,17 @@ int qd_multi_point_grad_f32(const QdDiffQuantDesc* table, int ntensors, int64_t 
  *   plus alpha/beta [num_buckets].  bucket in {64,128,256,512,1024,2048}; x 16-byte aligned.
  * qd_unpack_uniform_f32: y = (index/(levels-1))*alpha + beta -- bit-identical to the output of
  *   qd_uniform_f32 on the same input.  bucket: any power of two >= 8.
- * qd_histogram_u8: hist[j] = #{i : idx[i] == j}, j < k <= 256 (hist is overwritten). */
+ * qd_histogram_u8: hist[j] = #{i : idx[i] == j}, j < k <= 256 (hist is overwritten).
+ * qd_histogram_u8_ws: the same with a scratch buffer (8-byte aligned, qd_workspace_bytes() is enough; contents need no
+ *   initialisation): per-block totals go there and are summed per bin in a fixed order -- no global atomics. */
 int64_t qd_packed_bytes(int64_t n, int bits);
 int qd_pack_uniform_f32(const float* x, int64_t n, int64_t bucket, int levels, int bits, uint8_t* packed, float* alpha,
                         float* beta, void* stream);
 int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int levels, int bits, const float* alpha,
                           const float* beta, float* y, void* stream);
 int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream);
+int qd_histogram_u8_ws(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* ---- order statistics for initialize_quantization_points (quantization/help_functions.py:140-154: the reference
  * copies the scaled tensor to the host and calls np.percentile(a, linspace(0, 100, k)), which needs the two

@@ -74,6 +74,7 @@ SIGNATURES = {
     'qd_pack_uniform_f32': (c_int, [c_f, i64, i64, c_int, c_int, c_p, c_f, c_f, c_p]),
     'qd_unpack_uniform_f32': (c_int, [c_p, i64, i64, c_int, c_int, c_f, c_f, c_f, c_p]),
     'qd_histogram_u8': (c_int, [c_p, i64, c_int, c_p, c_p]),
+    'qd_histogram_u8_ws': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),
     'qd_order_stats_workspace_bytes': (ctypes.c_size_t, [c_int]),
     'qd_order_stats_f32': (c_int, [c_p, i64, c_p, c_int, c_p, c_p, ctypes.c_size_t, c_p]),
 }

@@ -67,7 +67,9 @@ def histogram_u8(idx, k):
         raise TypeError('histogram_u8 needs a uint8 tensor on a HIP device')
     idx = idx.contiguous()
     hist = torch.empty(k, dtype=torch.int64, device=idx.device)
-    _lib.check(_lib.load().qd_histogram_u8(idx.data_ptr(), idx.numel(), int(k), hist.data_ptr(), _lib.stream_ptr()))
+    ws = _lib.workspace(idx.device)
+    _lib.check(_lib.load().qd_histogram_u8_ws(idx.data_ptr(), idx.numel(), int(k), hist.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _lib.stream_ptr()))
     return hist
 
 

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     }
 
     // buckets after the vector part (the ragged last bucket): one DPP row each, last block
-    if (blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.x == 0) {                                    // (the first block, which starts first: the tail overlaps the bulk)
         const int row_id = threadIdx.x >> 4;                  // 16 rows per 256-thread block
         for (int64_t bkt = p.nvec + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
             const int64_t lo = bkt * p.row;
@@ -646,7 +646,7 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (blockIdx.x == gridDim.x - 1) {                 // buckets after the last whole chunk (incl. the ragged one)
+    if (blockIdx.x == 0) {                             // buckets after the last whole chunk (incl. the ragged one); block 0 starts first
         const int row_id = threadIdx.x >> 4;
         for (int64_t bkt = nchunks * m + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
             const int64_t lo = bkt * p.row;
@@ -665,9 +665,9 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
 // and finally every lane streams its float4s from LDS to HBM, coalesced.  (The first version transformed the register
 // copy and picked (alpha, beta) per element from the two candidate buckets: 48 VALU instructions per element against
 // 32 in the vector kernel, VALU-bound at 107-138 us for 64 Mi elements.)
-template <int MODE, int VMAX, bool PF = false>
+template <int MODE, int VMAX>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 6)))
-void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
+void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
     __shared__ PointTable Ts;
     const PointTable* T = nullptr;
     if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
@@ -677,7 +677,6 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
 
     const int B = (int)p.row;
     const int nf = (m * B) >> 2;                       // float4 per chunk (m % 4 == 0)
-    const int nj = (nf + 63) >> 6;
     const int mlanes = m < 64 ? m : 64;
     const int G = 64 / mlanes;                         // lanes per bucket (a power of two whenever it is > 1)
     const int bl = lane / G, sub = lane % G;
@@ -693,47 +692,27 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
     const int64_t wave = uniform_wave_index();
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 
-    // PF: the chunk a wave works on next is fetched into registers while the current one goes through its LDS phases
-    // (the loads of a wave otherwise only overlap with OTHER waves' phases); always issued, the chunk index clamped.
-    f4 vpf[PF ? VMAX : 1];
-    auto fetch_chunk = [&](int64_t c) {
-        const f4* src = (const f4*)(p.x + c * m * p.row);
-#pragma unroll
-        for (int j = 0; j < (PF ? VMAX : 0); ++j) {
-            const int f = lane + 64 * j;
-            vpf[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
-        }
-    };
-    if (PF && wave < nchunks) fetch_chunk(wave);
     for (int64_t c = wave; c < nchunks; c += nwaves) {
         const int64_t b0 = c * m;
         const int64_t e0 = b0 * p.row;
         const f4* src = (const f4*)(p.x + e0);
-        if (PF) {
-#pragma unroll
-            for (int j = 0; j < (PF ? VMAX : 0); ++j) {
-                const int f = lane + 64 * j;
-                if (j < nj && f < nf) {
-                    f4 t = vpf[j];
-                    if (!prescaled && prep_on) t = prep4(t, pp);
-                    ((f4*)vals)[f] = t;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_chunk(c + nwaves < nchunks ? c + nwaves : c);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
+        // Lane i of round j holds float4 (i + 64 j - h) of the chunk, h = the chunk's distance from the 128-byte line below
+        // it: every load and store instruction then covers eight whole lines instead of straddling nine (chunks start at
+        // arbitrary multiples of 16 bytes; measured on the one-wave-per-bucket kernel: 107.7 -> 100.1 us at bucket 1000).
+        // The launcher leaves room for the lead-in (nf + 7 <= VMAX * 64) or switches it off (lead = 0: sizes 506 .. 511).
+        const int h = lead ? (int)((e0 >> 2) & 7) : 0;
+        {
             f4 v[VMAX];
 #pragma unroll
             for (int j = 0; j < VMAX; ++j) {           // always-issued loads with a clamped address, as above
-                const int f = lane + 64 * j;
-                v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+                const int f = lane + 64 * j - h;
+                v[j] = __builtin_nontemporal_load(src + (f < 0 ? 0 : (f < nf ? f : nf - 1)));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < VMAX; ++j) {
-                const int f = lane + 64 * j;
-                if (j < nj && f < nf) {
+                const int f = lane + 64 * j - h;
+                if (f >= 0 && f < nf) {
                     if (!prescaled && prep_on) v[j] = prep4(v[j], pp);
                     ((f4*)vals)[f] = v[j];
                 }
@@ -809,14 +788,14 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
         f4* dst = (f4*)(p.out + e0);
 #pragma unroll
         for (int j = 0; j < VMAX; ++j) {
-            const int f = lane + 64 * j;
-            if (j < nj && f < nf) __builtin_nontemporal_store(((const f4*)vals)[f], dst + f);
+            const int f = lane + 64 * j - h;
+            if (f >= 0 && f < nf) __builtin_nontemporal_store(((const f4*)vals)[f], dst + f);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next chunk overwrites vals
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.x == 0) {
         const int row_id = threadIdx.x >> 4;
         for (int64_t bkt = nchunks * m + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
             const int64_t lo = bkt * p.row;
@@ -824,6 +803,108 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks) {
             bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
         }
     }
+}
+
+// ---- one wave per bucket, ANY bucket size above 256 (quantize-dequantize): 513, 1000, 1001, 2000, 3000, ... --------
+// The wave loads the 16-byte-aligned float4s that TOUCH its bucket [lo, hi) -- lane i holds float4 i, i + 64, ... counted
+// from the aligned element at or below lo, so a bucket that does not start on a 16-byte boundary shares its first and last
+// float4 with its neighbours (those two are fetched twice, the second time from L2) -- keeps them in registers, reduces
+// min / max over the elements that belong to the bucket (rounds that lie wholly inside take the unmasked path: a
+// wave-uniform test), and writes whole float4s with one 16-byte store, the up to 3 + 3 elements of the shared edge float4s
+// one by one.  One pass over HBM at any size, the short last bucket included (its final float4 is fetched whole: an
+// aligned 16-byte load that holds a valid element cannot cross a page, the bytes past the tensor are masked like a
+// neighbour's; nothing is ever stored outside the bucket) -- handing the last one or two buckets of a tensor to a 16-lane
+// group, as the kernels above do for their 256-element buckets, costs 60-130 us at bucket sizes of 3000-8000.  The chunk
+// kernels above stay for small buckets, where a wave per bucket would leave most lanes idle.  The float4 grid is aligned in ELEMENT index (the base pointer is 16-byte aligned), so the
+// stochastic draw of element e -- Philox block e >> 2, word e & 3 -- is the one every other kernel uses.
+template <int V>
+__global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
+    constexpr int MODE = MODE_QDQ;
+    const PointTable* T = nullptr;
+    const int lane = threadIdx.x & 63;
+    Prep pp;
+    pp.mean = p.mean ? *p.mean : 0.0f;
+    pp.me = p.me;
+    const bool prep_on = p.mean != nullptr || p.me != INFINITY;
+    const bool use_tab = !p.stochastic && p.sm1 <= 15.0f;
+    const float tab = (float)(lane & 15) / p.sm1;
+    const int64_t wave = uniform_wave_index();
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+
+    for (int64_t bkt = wave; bkt < nbk; bkt += nwaves) {
+        const int64_t lo = bkt * p.row;
+        const int row = (int)(lo + p.row <= p.n ? p.row : p.n - lo);   // the last bucket may be short
+        const int64_t a0 = lo & amask;                     // aligned element at or below lo (amask = ~31: a 128-byte line)
+        const int off = (int)(a0 - lo);                    // -31 .. 0: position of a0 relative to the bucket
+        const int nf = (int)(((lo + row + 3) >> 2) - (a0 >> 2));   // float4s from a0 to the bucket's last one
+        const f4* src = (const f4*)(p.x + a0);
+        f4 v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {                      // always issued, the index clamped (see k_bucket_chunk)
+            const int f = lane + 64 * j;
+            v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+        }
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            if (prep_on) v[j] = prep4(v[j], pp);
+            const int r0 = off + 4 * (lane + 64 * j);      // position of this float4's first element in the bucket
+            if (off + 256 * j >= 0 && off + 256 * (j + 1) <= row) {       // wave-uniform: the whole round is inside
+                mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j]));
+            } else {
+                const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool in = (unsigned)(r0 + c) < (unsigned)row;
+                    mn = pmin(mn, in ? xs[c] : INFINITY); mx = pmax(mx, in ? xs[c] : -INFINITY);
+                }
+            }
+        }
+        mn = wave_min(mn); mx = wave_max(mx);
+        float a, b;
+        alpha_beta(mn, mx, a, b);
+        if (lane == 0) {
+            if (p.alpha) p.alpha[bkt] = a;
+            if (p.beta) p.beta[bkt] = b;
+        }
+        const bool fast = fastdiv_ok(a);                   // a is wave-uniform
+        auto body = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            const float y = FAST ? 1.0f / a : 0.0f;        // RN(1/alpha), one IEEE division per bucket
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int f = lane + 64 * j;
+                const int r0 = off + 4 * f;
+                const int64_t e = a0 + 4 * (int64_t)f;     // element index of this float4 (a multiple of 4)
+                float side[4], o[4];
+                const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                if (use_tab) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = qdq_tab<FAST>(xs[c], a, b, p.sm1, pp.mean, side[c], tab, y);
+                } else {
+                    float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = transform<MODE, FAST>(p, T, xs[c], a, b, pp.mean, rnd[c], side[c], y);
+                }
+                if (r0 >= 0 && r0 + 4 <= row) {            // the float4 belongs to this bucket alone
+                    const f4 r = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(r, (f4*)(p.out + e));
+                    store_side4<MODE>(p, e, side);
+                } else {                                   // shared with a neighbour (or outside the bucket): own elements only
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if ((unsigned)(r0 + c) < (unsigned)row) {
+                            p.out[e + c] = o[c];
+                            store_side1<MODE>(p, e + c, side[c]);
+                        }
+                    }
+                }
+            }
+        };
+        if (fast) body(std::true_type{}); else body(std::false_type{});
+    }
+
 }
 
 // ---- generic path, small/medium rows: one lane group (16 lanes or a wave) per bucket, 256-thread
@@ -2046,7 +2127,9 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V, U>), dim3(blocks), dim3(256), 0, st, p); \
         return check_launch();                                                                  \
     }
-    if (aligned && p.nb > 1) {
+    static int no_vec = -1;
+    if (no_vec < 0) { const char* e = getenv("QD_NO_VEC"); no_vec = e ? atoi(e) : 0; }   // A/B: large vector sizes through k_bucket_wave_any
+    if (aligned && p.nb > 1 && !(no_vec && p.row > 256)) {
         switch (p.row) {
             case 64: QD_VEC(16, 1, 4)
             case 128: QD_VEC(16, 2, 2)
@@ -2061,6 +2144,45 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     }
 #undef QD_VEC
     p.nvec = 0;
+    if (MODE == MODE_QDQ && aligned && p.nb > 1 && p.row > 256 && p.row <= 8192) {
+        // one wave per bucket, any size (k_bucket_wave_any).  QD_WAVE_ANY=0: off (A/B), 1: sizes above 512 and sizes from 448
+        // that are not a multiple of 4 (multiples of 4 up to 512 stay with the chunk kernel: 300 -> 90 us against 127 us here),
+        // 2: every size above 256
+        static int sel = -1;
+        if (sel < 0) { const char* e = getenv("QD_WAVE_ANY"); sel = e ? atoi(e) : 1; }
+        const bool mult4 = (p.row & 3) == 0;
+        static int al = -1;
+        if (al < 0) { const char* e = getenv("QD_WAVE_ALIGN"); al = e ? atoi(e) : 32; if (al != 4 && al != 16 && al != 32 && al != 64) al = 32; }
+        const bool line_ok = (p.row * 4) % (al * 4) == 0;                        // every bucket starts on the boundary anyway
+        const int64_t amask = ~(int64_t)(al - 1);
+        // float4s a wave may have to hold: the bucket's own, +1 for a split first/last one, + the lead-in from the boundary
+        const int nf_max = (int)(p.row >> 2) + (mult4 ? 0 : 2) + (line_ok ? 0 : al / 4 - 1);
+        const int64_t nbk = p.nb;                                                // every bucket, the short last one included
+        if (sel > 0 && nf_max <= 64 * 32 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
+            const int blocks = blocks_for(nbk, 4);
+#define QD_WAVE_ANY(V)                                                                               \
+    {                                                                                                \
+        hipLaunchKernelGGL((k_bucket_wave_any<V>), dim3(blocks), dim3(256), 0, st, p, nbk, amask);   \
+        return check_launch();                                                                       \
+    }
+            if (nf_max <= 64 * 2) QD_WAVE_ANY(2)
+            if (nf_max <= 64 * 3) QD_WAVE_ANY(3)
+            if (nf_max <= 64 * 4) QD_WAVE_ANY(4)
+            if (nf_max <= 64 * 5) QD_WAVE_ANY(5)
+            if (nf_max <= 64 * 6) QD_WAVE_ANY(6)
+            if (nf_max <= 64 * 7) QD_WAVE_ANY(7)
+            if (nf_max <= 64 * 8) QD_WAVE_ANY(8)
+            if (nf_max <= 64 * 10) QD_WAVE_ANY(10)
+            if (nf_max <= 64 * 12) QD_WAVE_ANY(12)
+            if (nf_max <= 64 * 14) QD_WAVE_ANY(14)
+            if (nf_max <= 64 * 16) QD_WAVE_ANY(16)
+            if (nf_max <= 64 * 20) QD_WAVE_ANY(20)
+            if (nf_max <= 64 * 24) QD_WAVE_ANY(24)
+            if (nf_max <= 64 * 28) QD_WAVE_ANY(28)
+            QD_WAVE_ANY(32)
+#undef QD_WAVE_ANY
+        }
+    }
     // float4 per lane a chunk holds.  Measured at 64 Mi elements, bucket 100 / 36 / 300 / 1000 / 2000 (the one-bucket-
     // per-lane-group kernels below: 145 / 211 / 167 / 114 / 122 us): 16 -> 123 / 123 / 128 / 122 / 120 us (195 VGPRs,
     // two waves per SIMD: the load and the compute phase of a wave do not overlap); 8 -> 100 / 100 / 103 / 108 / 108;
@@ -2085,29 +2207,16 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row >= 4 && p.row * 4 <= (int64_t)kChunkV * 256) {
         // a multiple of 4 (chunks start 16-byte aligned), as many buckets as fit kChunkV * 256 elements: bucket 33 fills
         // 1980 of the 2048 elements with m = 60 instead of 1056 with m = 32
-        int m = (int)(((int64_t)kChunkV * 256) / p.row) & ~3;
+        int m = (int)(((int64_t)kChunkV * 256 - 28) / p.row) & ~3;        // - 28 elements: the lead-in to the 128-byte line
+        const int lead = m >= 4;
+        if (!lead) m = 4;                                                  // 506 .. 511: four buckets fill the chunk, no lead-in
         if (m > 256) m = 256;
         if (m < 64) { int p2 = 4; while (p2 * 2 <= m) p2 *= 2; if (m < 48 || p2 == m) m = p2; }
         const int64_t nchunks = nfull / m;
         if (nchunks > 0) {
             const size_t lds = (size_t)2 * (kChunkV * 128) * sizeof(float2);              // two waves: the staged chunk
             const int blocks = blocks_for(nchunks, 2) + 1;
-            static int pf_sel = -1;
-            if (pf_sel < 0) { const char* e = getenv("QD_CHUNK_PF"); pf_sel = e ? atoi(e) : 0; }   // prefetching variant (A/B)
-            if (MODE == MODE_QDQ && pf_sel) {
-                // persistent grid, pf_sel blocks per CU: a wave works through several chunks, fetching the next one early
-                static int cus = 0;
-                if (cus == 0) {
-                    int dev = 0;
-                    if (hipGetDevice(&dev) != hipSuccess ||
-                        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                        cus = 256;
-                }
-                const int64_t cap = (int64_t)cus * pf_sel;
-                const int pblocks = (int)(blocks - 1 < cap ? blocks - 1 : cap) + 1;
-                hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV, MODE == MODE_QDQ>), dim3(pblocks), dim3(128), lds, st, p, m, nchunks);
-            } else
-                hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks, lead);
             return check_launch();
         }
     }
@@ -2116,7 +2225,8 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         if (nchunks > 0) {
             const size_t lds = (size_t)2 * (16 * 128) * sizeof(float2);
             const int blocks = blocks_for(nchunks, 2) + 1;
-            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds, st, p, 4, nchunks);
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds, st, p, 4, nchunks,
+                               p.row * 4 + 28 <= 16 * 256 ? 1 : 0);
             return check_launch();
         }
     }

@@ -170,6 +170,66 @@ def test_uniform_chunk_kernels_many_chunks_per_wave(bucket):
     assert np.array_equal(host(qs), want['q'])
 
 
+@pytest.mark.parametrize('bucket', [257, 300, 511, 513, 600, 770, 1000, 1001, 1023, 1500, 2000, 2049, 3000, 4093, 5000, 6145,
+                                    8000, 8190])
+def test_uniform_wave_per_bucket_any_size(bucket):
+    """Bucket sizes above 256 that are not one of the vector sizes: one wave per bucket on the aligned float4s that touch
+    it (k_bucket_wave_any).  Tensor ends at, just after and well after a bucket boundary (the last buckets go to the tail
+    path when their final float4 would cross the end of the tensor); deterministic, stochastic, clamp + mean, level
+    indices; q, alpha, beta bit-exact against the C oracle."""
+    from quantized_distillation_amd import codec
+    rng = np.random.RandomState(bucket)
+    for extra in (0, 1, 2, 3, bucket // 2, bucket - 1):
+        n = bucket * 37 + extra
+        x = (rng.randn(n) * rng.choice([0.05, 1.0, 30.0])).astype(np.float32)
+        for s_ in (16, 256):
+            q, sf = quantization.uniformQuantization(dev(x), s_, bucket_size=bucket)
+            r = oc.uniform_quantize(x, s_, bucket)
+            assert np.array_equal(host(q), r['q']), (n, s_)
+            assert np.array_equal(host(sf.alpha).reshape(-1), r['alpha']) and np.array_equal(host(sf.beta).reshape(-1), r['beta'])
+            assert np.array_equal(host(sf.idx_min_rows).reshape(-1), r['imin']), (n, s_)
+    n = bucket * 301 + 2
+    x = rng.randn(n).astype(np.float32)
+    x[5] = np.nan                                                    # poisons bucket 0 only
+    xd = dev(x)
+    q, sf = quantization.uniformQuantization(xd, 16, bucket_size=bucket)
+    r = oc.uniform_quantize(x, 16, bucket)
+    assert np.array_equal(host(q), r['q'], equal_nan=True) and np.array_equal(host(sf.alpha).reshape(-1), r['alpha'], equal_nan=True)
+    x[5] = 0.25
+    xd = dev(x)
+    seed = quantization.quant_functions.next_stochastic_seed(peek=True)
+    qs, _ = quantization.uniformQuantization(xd, 16, bucket_size=bucket, stochastic_rounding=True)
+    rand = np.zeros(onp.bucket_geometry(n, bucket)[2], np.float32)
+    rand[:n] = onp.philox4x32_7_uniform(seed, n)
+    assert np.array_equal(host(qs), onp.uniform_quantize_stochastic(x, 16, rand, bucket)['q'])
+    q, sf = quantization.uniformQuantization(xd, 4, bucket_size=bucket, max_element=0.7, subtract_mean=True)
+    r = onp.uniform_quantize(x, 4, bucket, 0.7, True, mean=float(sf.mean_tensor))
+    assert np.array_equal(host(q), r['q']) and np.array_equal(host(sf.alpha).reshape(-1), r['alpha'].reshape(-1))
+    h = codec.level_histogram(xd, 16, bucket)
+    assert np.array_equal(host(h), np.bincount(oc.uniform_quantize(x, 16, bucket)['lev'], minlength=16))
+
+
+@pytest.mark.parametrize('bucket', [33, 255, 300, 506, 509, 511, 513, 1001, 1017, 1023])
+def test_other_modes_at_chunk_sizes(bucket):
+    """scale_down and nonUniformQuantization at bucket sizes of the chunk kernels (with and without the lead-in to the
+    128-byte line): bit-exact against the C oracle."""
+    rng = np.random.RandomState(bucket)
+    for n in (bucket * 41 + 3, bucket * 64, bucket * 1500 + bucket // 2):
+        x = rng.randn(n).astype(np.float32)
+        xd = dev(x)
+        pts = np.array([0.0, 0.3, 0.6, 1.0], np.float32)
+        q, idx, sf = quantization.nonUniformQuantization(xd, dev(pts), bucket_size=bucket)
+        r = oc.nonuniform_quantize(x, pts, bucket)
+        assert np.array_equal(host(q), r['q']) and np.array_equal(host(idx), r['idx']), (bucket, n)
+        sfn = quantization.ScalingFunction('linear', False, False, bucket)
+        u = sfn.scale_down(xd)
+        r2 = oc.scale_down(x, bucket)
+        assert np.array_equal(host(u).reshape(-1)[:n], r2['u']), (bucket, n)
+        assert np.array_equal(host(sfn.alpha).reshape(-1), r2['alpha']), (bucket, n)
+        if n % bucket:                                               # padding = the scaled last element
+            assert np.all(host(u).reshape(-1)[n:] == host(u).reshape(-1)[n - 1])
+
+
 def test_uniform_big_checksums_from_reference(golden_big):
     for c in golden_big:
         if c['op'] != 'uniform':
@@ -519,6 +579,12 @@ def test_level_histogram_and_device_huffman(golden_misc):
                 idx[::3] = rng.randint(0, k, size=len(idx[::3]))
             want = np.bincount(idx, minlength=256)[:k]
             assert np.array_equal(host(codec.histogram_u8(dev(idx), k)), want), (k, n)
+    # the entry point without a workspace (global atomics on a zeroed histogram) counts the same
+    idx = rng.randint(0, 100, size=(1 << 21) + 3).astype(np.uint8)
+    idx_d, out = dev(idx), torch.empty(128, dtype=torch.int64, device=DEV)
+    for k in (4, 16, 100, 128):
+        _lib.check(_lib.load().qd_histogram_u8(idx_d.data_ptr(), idx_d.numel(), k, out.data_ptr(), _lib.stream_ptr()))
+        assert np.array_equal(host(out)[:k], np.bincount(idx, minlength=256)[:k]), k
     runs = np.repeat(np.arange(7, dtype=np.uint8), 100000)                  # long runs: all four bytes of a word equal
     assert np.array_equal(host(codec.histogram_u8(dev(runs), 256)), np.bincount(runs, minlength=256))
     # same Huffman mean code length as the reference computed through its digitize path
@@ -530,9 +596,9 @@ def test_level_histogram_and_device_huffman(golden_misc):
             assert abs(got - c['mean_bit_length']) < 1e-12, (c, got)
 
 
-def test_histogram_u16_epoch_flush():
-    """k > 64 counts in uint16 columns that are flushed before a lane can have seen 65535 symbols; that only
-    happens beyond ~4.2 G symbols.  A periodic pattern gives the expected counts without a host pass."""
+def test_histogram_of_4_5_billion_symbols():
+    """4.5 G symbols (past 2^32): 64-bit totals, uint32 per-block counters that one block cannot overflow in one launch.
+    A periodic pattern gives the expected counts without a host pass."""
     from quantized_distillation_amd import codec
     reps = 18_000_000
     x = torch.arange(251, dtype=torch.uint8, device=DEV).repeat(reps)      # 4.5 GB
@@ -540,7 +606,7 @@ def test_histogram_u16_epoch_flush():
     want = torch.zeros(256, dtype=torch.int64)
     want[:251] = reps
     assert torch.equal(h.cpu(), want)
-    h = codec.histogram_u8(x[1:], 256)                                       # unaligned: scalar path, lane-local flush
+    h = codec.histogram_u8(x[1:], 256)                                       # unaligned: byte loads
     want[0] -= 1
     assert torch.equal(h.cpu(), want)
 
