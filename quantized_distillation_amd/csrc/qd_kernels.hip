@@ -336,6 +336,27 @@ __device__ __forceinline__ void bucket_row16(const KParams& p, const PointTable*
     bucket_lanes<MODE, 16>(p, T, bkt, lo, hi, l, pp);
 }
 
+// The buckets a kernel's main path leaves over (from `first` on: the ragged last bucket, the full ones after the last whole
+// tile / chunk), done by ONE block: a DPP row each for buckets up to 256 elements, a whole wave each above that -- a
+// 16-lane group needs 2 x 500 dependent iterations for an 8000-element bucket (measured: 60-130 us at the end of a
+// 64 Mi-element launch when the LAST block did it; the caller is block 0, which starts first, so the tail overlaps the bulk).
+template <int MODE>
+__device__ __forceinline__ void tail_buckets(const KParams& p, const PointTable* T, int64_t first, const Prep& pp) {
+    if (p.row > 256) {
+        for (int64_t bkt = first + (threadIdx.x >> 6); bkt < p.nb; bkt += (blockDim.x >> 6)) {
+            const int64_t lo = bkt * p.row;
+            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+            bucket_lanes<MODE, 64>(p, T, bkt, lo, hi, threadIdx.x & 63, pp);
+        }
+    } else {
+        for (int64_t bkt = first + (threadIdx.x >> 4); bkt < p.nb; bkt += (blockDim.x >> 4)) {
+            const int64_t lo = bkt * p.row;
+            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+            bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
+        }
+    }
+}
+
 // ---- vector path: LPB lanes per bucket, V float4 per lane: bucket = LPB*V*4 elements ---------
 // LPB == 16: a DPP row owns a bucket; LPB == 64: the whole wave owns a bucket (large buckets).
 // U = consecutive buckets each lane group handles per tile, so that a wave always streams 4 KiB
@@ -503,12 +524,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
 
     // buckets after the vector part (the ragged last bucket): one DPP row each, last block
     if (blockIdx.x == 0) {                                    // (the first block, which starts first: the tail overlaps the bulk)
-        const int row_id = threadIdx.x >> 4;                  // 16 rows per 256-thread block
-        for (int64_t bkt = p.nvec + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
-            const int64_t lo = bkt * p.row;
-            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
-            bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
-        }
+        tail_buckets<MODE>(p, T, p.nvec, pp);
     }
 }
 
@@ -647,17 +663,21 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
     }
 
     if (blockIdx.x == 0) {                             // buckets after the last whole chunk (incl. the ragged one); block 0 starts first
-        const int row_id = threadIdx.x >> 4;
-        for (int64_t bkt = nchunks * m + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
-            const int64_t lo = bkt * p.row;
-            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
-            if (hi - lo == p.row) bucket_lanes4<MODE, 16>(p, T, bkt, lo, threadIdx.x & 15, pp);   // full: float4 accesses
-            else bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
+        if (p.row > 256) {
+            tail_buckets<MODE>(p, T, nchunks * m, pp);
+        } else {
+            const int row_id = threadIdx.x >> 4;
+            for (int64_t bkt = nchunks * m + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
+                const int64_t lo = bkt * p.row;
+                const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
+                if (hi - lo == p.row) bucket_lanes4<MODE, 16>(p, T, bkt, lo, threadIdx.x & 15, pp);   // full: float4 accesses
+                else bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
+            }
         }
     }
 }
 
-// Same for bucket sizes that are NOT a multiple of 4 (33, 50, 7, ... >= 4): m is a multiple of 4, so every chunk
+// Same for bucket sizes that are NOT a multiple of 4 (33, 50, 7, 3, 1, ...): m is a multiple of 4, so every chunk
 // still starts 16-byte aligned and holds a whole number of float4, but a float4 may straddle two buckets.  So the
 // registers only carry the chunk between HBM and LDS: the prepared values are staged in LDS (16 B per float4), the lane
 // (group) that reduces a bucket goes straight on to TRANSFORM it in place in LDS -- alpha, beta and 1/alpha are then
@@ -795,14 +815,7 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (blockIdx.x == 0) {
-        const int row_id = threadIdx.x >> 4;
-        for (int64_t bkt = nchunks * m + row_id; bkt < p.nb; bkt += (blockDim.x >> 4)) {
-            const int64_t lo = bkt * p.row;
-            const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
-            bucket_row16<MODE>(p, T, bkt, lo, hi, threadIdx.x & 15, pp);
-        }
-    }
+    if (blockIdx.x == 0) tail_buckets<MODE>(p, T, nchunks * m, pp);
 }
 
 // ---- one wave per bucket, ANY bucket size above 256 (quantize-dequantize): 513, 1000, 1001, 2000, 3000, ... --------
@@ -2204,13 +2217,13 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             return check_launch();
         }
     }
-    if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row >= 4 && p.row * 4 <= (int64_t)kChunkV * 256) {
+    if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row * 4 <= (int64_t)kChunkV * 256) {
         // a multiple of 4 (chunks start 16-byte aligned), as many buckets as fit kChunkV * 256 elements: bucket 33 fills
         // 1980 of the 2048 elements with m = 60 instead of 1056 with m = 32
         int m = (int)(((int64_t)kChunkV * 256 - 28) / p.row) & ~3;        // - 28 elements: the lead-in to the 128-byte line
         const int lead = m >= 4;
         if (!lead) m = 4;                                                  // 506 .. 511: four buckets fill the chunk, no lead-in
-        if (m > 256) m = 256;
+        // (no upper limit on m: the kernel keeps no per-bucket table; bucket sizes 1, 2, 3, 5, 7 fill the chunk too)
         if (m < 64) { int p2 = 4; while (p2 * 2 <= m) p2 *= 2; if (m < 48 || p2 == m) m = p2; }
         const int64_t nchunks = nfull / m;
         if (nchunks > 0) {

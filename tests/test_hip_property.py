@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 SOAK = int(os.environ.get('QD_SOAK', '1'))        # QD_SOAK=10 multiplies the number of examples (soak runs)
 
-buckets = st.sampled_from([None, 256, 256, 64, 128, 512, 1024, 2048, 4096, 100, 7, 1, 33, 1000, 4, 12, 36, 300, 2000, 8192, 8196, 5, 50, 250, 511, 513, 3, 1001, 1023])
+buckets = st.sampled_from([None, 256, 256, 64, 128, 512, 1024, 2048, 4096, 100, 7, 1, 33, 1000, 4, 12, 36, 300, 2000, 8192, 8196, 5, 50, 250, 511, 513, 3, 1001, 1023, 450, 509, 770, 3000, 5003, 8190])
 sizes = st.one_of(st.integers(1, 5000), st.integers(5000, 300000))
 levels = st.sampled_from([2, 3, 4, 7, 16, 16, 255, 256, 1000])
 

@@ -89,9 +89,9 @@ timeit('K1  uniform 4-bit bucket 256, weight-like 0.05*randn', lambda i: live.__
 del xw
 timeit('K1g uniform 4-bit no buckets (API, 3 launches)', k1g, 12)
 timeit('K1s uniform 4-bit bucket 256 stochastic', k1s, 8)
-for b in (64, 128, 512, 1024, 2048, 100):
+for b in (64, 128, 512, 1024, 2048, 4096, 8192, 100, 36, 33, 50, 250, 513, 1000, 1001, 2000, 3000, 5000, 8000):
     timeit('K1  uniform 4-bit bucket %d' % b, lambda i, b=b: live.__setitem__(i % R, quantization.uniformQuantization(xs[i % R], 16, bucket_size=b)[0]), 8,
-           iters=10 if b == 100 else 40)
+           iters=40 if b in (64, 128, 512, 1024, 2048) else 12)
 
 sf = quantization.ScalingFunction('linear', False, False, 256)
 us = [None] * R

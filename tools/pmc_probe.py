@@ -36,6 +36,12 @@ record('K1 uniform 4-bit bucket 100 (chunk kernel)', 'k_bucket_chunk<0, 8>', 8 *
        lambda i: keep.append(quantization.uniformQuantization(xs[i + 3], 16, bucket_size=100)[0]))
 record('K1 uniform 4-bit bucket 33 (chunk_any kernel)', 'k_bucket_chunk_any<0, 8>', 8 * N,
        lambda i: keep.append(quantization.uniformQuantization(xs[i], 16, bucket_size=33)[0]))
+record('K1 uniform 4-bit bucket 1000 (one wave per bucket, any size)', 'k_bucket_wave_any<5>', 8 * N,
+       lambda i: keep.append(quantization.uniformQuantization(xs[i + 3], 16, bucket_size=1000)[0]))
+record('K1 uniform 4-bit bucket 513 (one wave per bucket, any size)', 'k_bucket_wave_any<3>', 8 * N,
+       lambda i: keep.append(quantization.uniformQuantization(xs[i], 16, bucket_size=513)[0]))
+lev = [torch.randint(0, 16, (N,), dtype=torch.uint8, device=dev) for _ in range(3)]
+record('HST level histogram k=16 (LDS integer atomics + fold)', 'k_hist_atomic<2>', N, lambda i: keep.append(codec.histogram_u8(lev[i], 16)))
 sf = quantization.ScalingFunction('linear', False, False, 256)
 record('K2 scale_down', 'k_bucket_vec<1, 16, 4, 1>', 8 * N, lambda i: keep.append(sf.scale_down(xs[i + 3])))
 u = sf.scale_down(xs[0])
