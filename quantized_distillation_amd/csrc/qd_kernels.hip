@@ -2223,7 +2223,10 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         int m = (int)(((int64_t)kChunkV * 256 - 28) / p.row) & ~3;        // - 28 elements: the lead-in to the 128-byte line
         const int lead = m >= 4;
         if (!lead) m = 4;                                                  // 506 .. 511: four buckets fill the chunk, no lead-in
-        // (no upper limit on m: the kernel keeps no per-bucket table; bucket sizes 1, 2, 3, 5, 7 fill the chunk too)
+        // (no upper limit on m: the kernel keeps no per-bucket table; bucket sizes 1, 2, 3, 5, 7 fill the chunk too.  Above 64
+        // buckets every lane reduces whole buckets alone: a multiple of 64 keeps all lanes busy in every round -- bucket 7:
+        // 102 us with m = 256, 107-110 us with m = 288)
+        if (m >= 64) m &= ~63;
         if (m < 64) { int p2 = 4; while (p2 * 2 <= m) p2 *= 2; if (m < 48 || p2 == m) m = p2; }
         const int64_t nchunks = nfull / m;
         if (nchunks > 0) {
