@@ -818,7 +818,7 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
     if (blockIdx.x == 0) tail_buckets<MODE>(p, T, nchunks * m, pp);
 }
 
-// ---- one wave per bucket, ANY bucket size above 256 (quantize-dequantize): 513, 1000, 1001, 2000, 3000, ... --------
+// ---- one wave per bucket, ANY bucket size above 256 (every mode): 513, 1000, 1001, 2000, 3000, ... ---------------
 // The wave loads the 16-byte-aligned float4s that TOUCH its bucket [lo, hi) -- lane i holds float4 i, i + 64, ... counted
 // from the aligned element at or below lo, so a bucket that does not start on a 16-byte boundary shares its first and last
 // float4 with its neighbours (those two are fetched twice, the second time from L2) -- keeps them in registers, reduces
@@ -830,16 +830,18 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
 // group, as the kernels above do for their 256-element buckets, costs 60-130 us at bucket sizes of 3000-8000.  The chunk
 // kernels above stay for small buckets, where a wave per bucket would leave most lanes idle.  The float4 grid is aligned in ELEMENT index (the base pointer is 16-byte aligned), so the
 // stochastic draw of element e -- Philox block e >> 2, word e & 3 -- is the one every other kernel uses.
-template <int V>
+template <int MODE, int V>
 __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
-    constexpr int MODE = MODE_QDQ;
+    __shared__ PointTable Ts;
     const PointTable* T = nullptr;
+    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
     const int lane = threadIdx.x & 63;
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
-    const bool prep_on = p.mean != nullptr || p.me != INFINITY;
-    const bool use_tab = !p.stochastic && p.sm1 <= 15.0f;
+    const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
+    const bool prep_on = !prescaled && (p.mean != nullptr || p.me != INFINITY);
+    const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
     const float tab = (float)(lane & 15) / p.sm1;
     const int64_t wave = uniform_wave_index();
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -857,30 +859,34 @@ __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk,
             const int f = lane + 64 * j;
             v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
         }
-        float mn = INFINITY, mx = -INFINITY;
+        float a, b;
+        if (prescaled) {                                   // x is u, alpha / beta are inputs
+            a = p.alpha[bkt]; b = p.beta[bkt];
+        } else {
+            float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            if (prep_on) v[j] = prep4(v[j], pp);
-            const int r0 = off + 4 * (lane + 64 * j);      // position of this float4's first element in the bucket
-            if (off + 256 * j >= 0 && off + 256 * (j + 1) <= row) {       // wave-uniform: the whole round is inside
-                mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j]));
-            } else {
-                const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            for (int j = 0; j < V; ++j) {
+                if (prep_on) v[j] = prep4(v[j], pp);
+                const int r0 = off + 4 * (lane + 64 * j);  // position of this float4's first element in the bucket
+                if (off + 256 * j >= 0 && off + 256 * (j + 1) <= row) {   // wave-uniform: the whole round is inside
+                    mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j]));
+                } else {
+                    const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool in = (unsigned)(r0 + c) < (unsigned)row;
-                    mn = pmin(mn, in ? xs[c] : INFINITY); mx = pmax(mx, in ? xs[c] : -INFINITY);
+                    for (int c = 0; c < 4; ++c) {
+                        const bool in = (unsigned)(r0 + c) < (unsigned)row;
+                        mn = pmin(mn, in ? xs[c] : INFINITY); mx = pmax(mx, in ? xs[c] : -INFINITY);
+                    }
                 }
             }
+            mn = wave_min(mn); mx = wave_max(mx);
+            alpha_beta(mn, mx, a, b);
+            if (lane == 0) {
+                if (p.alpha) p.alpha[bkt] = a;
+                if (p.beta) p.beta[bkt] = b;
+            }
         }
-        mn = wave_min(mn); mx = wave_max(mx);
-        float a, b;
-        alpha_beta(mn, mx, a, b);
-        if (lane == 0) {
-            if (p.alpha) p.alpha[bkt] = a;
-            if (p.beta) p.beta[bkt] = b;
-        }
-        const bool fast = fastdiv_ok(a);                   // a is wave-uniform
+        const bool fast = MODE == MODE_QDQ && fastdiv_ok(a);   // a is wave-uniform
         auto body = [&](auto fast_c) {
             constexpr bool FAST = decltype(fast_c)::value;
             const float y = FAST ? 1.0f / a : 0.0f;        // RN(1/alpha), one IEEE division per bucket
@@ -896,11 +902,18 @@ __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk,
                     for (int c = 0; c < 4; ++c) o[c] = qdq_tab<FAST>(xs[c], a, b, p.sm1, pp.mean, side[c], tab, y);
                 } else {
                     float rnd[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
+                    if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = transform<MODE, FAST>(p, T, xs[c], a, b, pp.mean, rnd[c], side[c], y);
+                    for (int c = 0; c < 4; ++c) {
+                        side[c] = 0.0f;
+                        o[c] = transform<MODE, FAST>(p, T, xs[c], a, b, pp.mean, rnd[c], side[c], y);
+                    }
                 }
-                if (r0 >= 0 && r0 + 4 <= row) {            // the float4 belongs to this bucket alone
+                if (off + 256 * j >= 0 && off + 256 * (j + 1) <= row) {    // wave-uniform: the whole round is inside the bucket
+                    const f4 r = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(r, (f4*)(p.out + e));
+                    store_side4_row<MODE>(p, e, side);     // every DPP row holds 16 consecutive float4s, all lanes active
+                } else if (r0 >= 0 && r0 + 4 <= row) {     // the float4 belongs to this bucket alone
                     const f4 r = {o[0], o[1], o[2], o[3]};
                     __builtin_nontemporal_store(r, (f4*)(p.out + e));
                     store_side4<MODE>(p, e, side);
@@ -916,8 +929,14 @@ __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk,
             }
         };
         if (fast) body(std::true_type{}); else body(std::false_type{});
+        if (MODE == MODE_SCALE && row < (int)p.row) {
+            // scale_down returns the padded layout: the short last bucket is filled up with copies of the scaled last
+            // element (ref: help_functions.py:76-86)
+            float ul = (prep_on ? prep(p.x[p.n - 1], pp) : p.x[p.n - 1]) - b;
+            ul = ul / a;
+            for (int64_t i = lo + row + lane; i < lo + p.row; i += 64) p.out[i] = ul;
+        }
     }
-
 }
 
 // ---- generic path, small/medium rows: one lane group (16 lanes or a wave) per bucket, 256-thread
@@ -2157,7 +2176,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     }
 #undef QD_VEC
     p.nvec = 0;
-    if (MODE == MODE_QDQ && aligned && p.nb > 1 && p.row > 256 && p.row <= 8192) {
+    if (aligned && p.nb > 1 && p.row > 256 && p.row <= 8192) {
         // one wave per bucket, any size (k_bucket_wave_any).  QD_WAVE_ANY=0: off (A/B), 1: sizes above 512 and sizes from 448
         // that are not a multiple of 4 (multiples of 4 up to 512 stay with the chunk kernel: 300 -> 90 us against 127 us here),
         // 2: every size above 256
@@ -2173,26 +2192,36 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         const int64_t nbk = p.nb;                                                // every bucket, the short last one included
         if (sel > 0 && nf_max <= 64 * 32 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
             const int blocks = blocks_for(nbk, 4);
-#define QD_WAVE_ANY(V)                                                                               \
-    {                                                                                                \
-        hipLaunchKernelGGL((k_bucket_wave_any<V>), dim3(blocks), dim3(256), 0, st, p, nbk, amask);   \
-        return check_launch();                                                                       \
+#define QD_WAVE_ANY(V)                                                                                     \
+    {                                                                                                      \
+        hipLaunchKernelGGL((k_bucket_wave_any<MODE, V>), dim3(blocks), dim3(256), 0, st, p, nbk, amask);   \
+        return check_launch();                                                                             \
     }
-            if (nf_max <= 64 * 2) QD_WAVE_ANY(2)
-            if (nf_max <= 64 * 3) QD_WAVE_ANY(3)
-            if (nf_max <= 64 * 4) QD_WAVE_ANY(4)
-            if (nf_max <= 64 * 5) QD_WAVE_ANY(5)
-            if (nf_max <= 64 * 6) QD_WAVE_ANY(6)
-            if (nf_max <= 64 * 7) QD_WAVE_ANY(7)
-            if (nf_max <= 64 * 8) QD_WAVE_ANY(8)
-            if (nf_max <= 64 * 10) QD_WAVE_ANY(10)
-            if (nf_max <= 64 * 12) QD_WAVE_ANY(12)
-            if (nf_max <= 64 * 14) QD_WAVE_ANY(14)
-            if (nf_max <= 64 * 16) QD_WAVE_ANY(16)
-            if (nf_max <= 64 * 20) QD_WAVE_ANY(20)
-            if (nf_max <= 64 * 24) QD_WAVE_ANY(24)
-            if (nf_max <= 64 * 28) QD_WAVE_ANY(28)
-            QD_WAVE_ANY(32)
+            if constexpr (MODE == MODE_QDQ) {              // the hot mode: rounds in steps of one up to 8
+                if (nf_max <= 64 * 2) QD_WAVE_ANY(2)
+                if (nf_max <= 64 * 3) QD_WAVE_ANY(3)
+                if (nf_max <= 64 * 4) QD_WAVE_ANY(4)
+                if (nf_max <= 64 * 5) QD_WAVE_ANY(5)
+                if (nf_max <= 64 * 6) QD_WAVE_ANY(6)
+                if (nf_max <= 64 * 7) QD_WAVE_ANY(7)
+                if (nf_max <= 64 * 8) QD_WAVE_ANY(8)
+                if (nf_max <= 64 * 10) QD_WAVE_ANY(10)
+                if (nf_max <= 64 * 12) QD_WAVE_ANY(12)
+                if (nf_max <= 64 * 14) QD_WAVE_ANY(14)
+                if (nf_max <= 64 * 16) QD_WAVE_ANY(16)
+                if (nf_max <= 64 * 20) QD_WAVE_ANY(20)
+                if (nf_max <= 64 * 24) QD_WAVE_ANY(24)
+                if (nf_max <= 64 * 28) QD_WAVE_ANY(28)
+                QD_WAVE_ANY(32)
+            } else {                                       // scale_down, nearest point: fewer instances
+                if (nf_max <= 64 * 3) QD_WAVE_ANY(3)
+                if (nf_max <= 64 * 5) QD_WAVE_ANY(5)
+                if (nf_max <= 64 * 8) QD_WAVE_ANY(8)
+                if (nf_max <= 64 * 12) QD_WAVE_ANY(12)
+                if (nf_max <= 64 * 16) QD_WAVE_ANY(16)
+                if (nf_max <= 64 * 24) QD_WAVE_ANY(24)
+                QD_WAVE_ANY(32)
+            }
 #undef QD_WAVE_ANY
         }
     }

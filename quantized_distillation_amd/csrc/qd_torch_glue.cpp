@@ -247,6 +247,10 @@ PyObject* glue_uniform_common(PyObject*, PyObject* const* args, Py_ssize_t nargs
         for (auto& c : g_slabs)
             if (c.device == dev.index() && c.stream == stream) { sl = &c; break; }
         if (!sl) {
+            if (g_slabs.size() >= 64) {                   // programs that keep creating streams: forget the oldest entry (its
+                Py_XDECREF(g_slabs.front().py);           // slab lives on through whatever was carved from it)
+                g_slabs.erase(g_slabs.begin());
+            }
             g_slabs.push_back({static_cast<int>(dev.index()), stream, at::Tensor(), nullptr, kSlabFloats});
             sl = &g_slabs.back();
         }

@@ -85,3 +85,26 @@ def test_native_glue_loads_and_fails_loudly_on_cpu_tensors():
     import quantization
     with pytest.raises(RuntimeError, match='no CPU path'):
         quantization.uniformQuantization(torch.zeros(8), 16, bucket_size=4)
+
+
+def test_glue_common_path_declines_what_it_does_not_handle():
+    """glue.uniform_common (the native common-case entry point of uniformQuantization) returns None -- "take the general
+    path" -- for anything but a contiguous fp32 device tensor with exact-int arguments; on this CPU box that is every call,
+    so the general path's errors are what a caller sees."""
+    import numpy as np
+    import torch
+    import quantization
+    from quantization.quant_functions import ScalingFunction
+    g = _lib.glue()
+    with pytest.raises(TypeError):
+        g.register(3)
+    g.register(ScalingFunction)
+    x = torch.zeros(8)
+    for args in ((x, 16, 256), (x, 16, None), (x.double(), 16, 4), (x, 16.0, 4), (x, np.int64(16), 4), (x, True, 4),
+                 (x, 16, True), (x, 16, 0), (x, 16, -1), (x, 1, 4), (x, 2 ** 40, 4), (x, 16, 2 ** 70), ('x', 16, 4),
+                 (x, 16), (x, 16, 4, 5)):
+        assert g.uniform_common(*args) is None, args
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        quantization.uniformQuantization(x, 16, bucket_size=4)
+    with pytest.raises(ValueError):
+        quantization.uniformQuantization(x, 16, bucket_size=True)

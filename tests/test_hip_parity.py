@@ -209,12 +209,12 @@ def test_uniform_wave_per_bucket_any_size(bucket):
     assert np.array_equal(host(h), np.bincount(oc.uniform_quantize(x, 16, bucket)['lev'], minlength=16))
 
 
-@pytest.mark.parametrize('bucket', [33, 255, 300, 506, 509, 511, 513, 1001, 1017, 1023])
+@pytest.mark.parametrize('bucket', [33, 255, 300, 506, 509, 511, 513, 1000, 1001, 1017, 1023, 2000, 3001, 5000, 8190])
 def test_other_modes_at_chunk_sizes(bucket):
     """scale_down and nonUniformQuantization at bucket sizes of the chunk kernels (with and without the lead-in to the
     128-byte line): bit-exact against the C oracle."""
     rng = np.random.RandomState(bucket)
-    for n in (bucket * 41 + 3, bucket * 64, bucket * 1500 + bucket // 2):
+    for n in (bucket * 41 + 3, bucket * 64, bucket * 300 + bucket // 2, bucket * 7 + 1):
         x = rng.randn(n).astype(np.float32)
         xd = dev(x)
         pts = np.array([0.0, 0.3, 0.6, 1.0], np.float32)
@@ -228,6 +228,16 @@ def test_other_modes_at_chunk_sizes(bucket):
         assert np.array_equal(host(sfn.alpha).reshape(-1), r2['alpha']), (bucket, n)
         if n % bucket:                                               # padding = the scaled last element
             assert np.all(host(u).reshape(-1)[n:] == host(u).reshape(-1)[n - 1])
+        # the pre-processed forward (u resident, midpoint rule, 64 points: the grid-narrowed search) and the point gradient
+        pts64 = np.sort(rng.rand(64)).astype(np.float32)
+        fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=xd)
+        qm = fn.forward(None, dev(pts64))
+        rm = oc.nonuniform_quantize(x, pts64, bucket, 'midpoint')
+        assert np.array_equal(host(qm), rm['q']) and np.array_equal(host(fn.savedForBackward['indices']), rm['idx']), (bucket, n)
+        g = rng.randn(n).astype(np.float32)
+        _, gp = fn.backward(dev(g))
+        want, absum = oc.point_grad(g, rm['idx'], rm['alpha'], bucket, 64)
+        assert np.all(np.abs(host(gp).astype(np.float64) - want) <= 4e-6 * absum + 1e-30), (bucket, n)
 
 
 def test_uniform_big_checksums_from_reference(golden_big):
