@@ -216,14 +216,17 @@ int qd_multi_point_grad_f32(const QdDiffQuantDesc* table, int ntensors, int64_t 
  *   indices, `bits` (1, 2, 4 or 8; levels <= 2^bits) per element, element e in bits
  *   [e*bits, (e+1)*bits) of `packed` (qd_packed_bytes(n, bits) bytes, little endian inside a byte),
  *   plus alpha/beta [num_buckets].  bucket in {64,128,256,512,1024,2048}; x 16-byte aligned.
+ * qd_pack_levels_u8: the same packing for level indices that are already there (the level_idx output of qd_uniform_f32):
+ *   together they give the packed form at ANY bucket size, bucket 0 = none included.
  * qd_unpack_uniform_f32: y = (index/(levels-1))*alpha + beta -- bit-identical to the output of
- *   qd_uniform_f32 on the same input.  bucket: any power of two >= 8.
+ *   qd_uniform_f32 on the same input.  Any bucket size (0: one alpha / beta for the tensor).
  * qd_histogram_u8: hist[j] = #{i : idx[i] == j}, j < k <= 256 (hist is overwritten).
  * qd_histogram_u8_ws: the same with a scratch buffer (8-byte aligned, qd_workspace_bytes() is enough; contents need no
  *   initialisation): per-block totals go there and are summed per bin in a fixed order -- no global atomics. */
 int64_t qd_packed_bytes(int64_t n, int bits);
 int qd_pack_uniform_f32(const float* x, int64_t n, int64_t bucket, int levels, int bits, uint8_t* packed, float* alpha,
                         float* beta, void* stream);
+int qd_pack_levels_u8(const uint8_t* levels_idx, int64_t n, int bits, uint8_t* packed, void* stream);
 int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int levels, int bits, const float* alpha,
                           const float* beta, float* y, void* stream);
 int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     'qd_multi_point_grad_f32': (c_int, [c_p, c_int, i64, i64, c_int, c_f, c_p, c_size, c_p]),
     'qd_packed_bytes': (i64, [i64, c_int]),
     'qd_pack_uniform_f32': (c_int, [c_f, i64, i64, c_int, c_int, c_p, c_f, c_f, c_p]),
+    'qd_pack_levels_u8': (c_int, [c_p, i64, c_int, c_p, c_p]),
     'qd_unpack_uniform_f32': (c_int, [c_p, i64, i64, c_int, c_int, c_f, c_f, c_f, c_p]),
     'qd_histogram_u8': (c_int, [c_p, i64, c_int, c_p, c_p]),
     'qd_histogram_u8_ws': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),

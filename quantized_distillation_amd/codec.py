@@ -37,27 +37,49 @@ class PackedUniform(object):
         n = self.shape.numel()
         y = torch.empty(n, dtype=torch.float32, device=self.packed.device)
         if n > 0:
-            _lib.check(_lib.load().qd_unpack_uniform_f32(self.packed.data_ptr(), n, self.bucket_size, self.s, self.bits,
+            _lib.check(_lib.load().qd_unpack_uniform_f32(self.packed.data_ptr(), n, self.bucket_size or 0, self.s, self.bits,
                                                          self.alpha.data_ptr(), self.beta.data_ptr(), y.data_ptr(),
                                                          _lib.stream_ptr()))
         return y.view(self.shape)
 
 
+_FUSED_BUCKETS = (64, 128, 256, 512, 1024, 2048)
+
+
 def pack_uniform(tensor, s, bucket_size=256, bits=None):
-    """Quantize `tensor` with `s` levels per bucket and keep only the packed level indices."""
+    """Quantize `tensor` with `s` levels per bucket and keep only the packed level indices (+ alpha / beta per bucket).
+    Bucket sizes 64 ... 2048 (powers of two) take one fused kernel (4 B read + bits/8 B written per element); any other
+    bucket size -- and bucket_size=None -- quantizes with the level-index side output of the quantize kernel and packs
+    those (qd_uniform_f32 + qd_pack_levels_u8): the same bytes, whatever the bucket geometry."""
     _lib.require_device_f32(tensor)
-    if bucket_size not in (64, 128, 256, 512, 1024, 2048):
-        raise ValueError('the packed format is defined for bucket sizes 64..2048 (powers of two)')
+    if bucket_size is not None and (not isinstance(bucket_size, int) or isinstance(bucket_size, bool) or bucket_size <= 0):
+        raise ValueError('Bucket size must be an integer and strictly positive. Pass None if you want to avoid using buckets')
+    if int(s) != s or s < 2:
+        raise ValueError('s must be an integer >= 2')
     bits = bits_for_levels(s) if bits is None else bits
+    if bits not in (1, 2, 4, 8) or s > (1 << bits):
+        raise ValueError('bits must be 1, 2, 4 or 8 and hold s levels')
+    if _lib.on_other_device(tensor):
+        with torch.cuda.device(tensor.device):
+            return pack_uniform(tensor, s, bucket_size, bits)
     x = tensor.contiguous()
     n = x.numel()
     lib = _lib.load()
-    nb = max(1, -(-n // bucket_size))
-    packed = torch.empty(int(lib.qd_packed_bytes(n, bits)) + 8, dtype=torch.uint8, device=x.device)[:int(lib.qd_packed_bytes(n, bits))]
+    nb = 1 if (bucket_size is None or n < bucket_size) else -(-n // bucket_size)
+    nbytes = int(lib.qd_packed_bytes(n, bits))
+    packed = torch.empty(nbytes + 8, dtype=torch.uint8, device=x.device)[:nbytes]
     ab = torch.empty(2, nb, dtype=torch.float32, device=x.device)
-    if n > 0:
+    if n > 0 and bucket_size in _FUSED_BUCKETS and x.data_ptr() % 16 == 0:
         _lib.check(lib.qd_pack_uniform_f32(x.data_ptr(), n, bucket_size, int(s), bits, packed.data_ptr(),
                                            ab[0].data_ptr(), ab[1].data_ptr(), _lib.stream_ptr()))
+    elif n > 0:
+        lev = torch.empty(n, dtype=torch.uint8, device=x.device)
+        q = torch.empty_like(x)
+        ws = _lib.workspace(x.device)
+        _lib.check(lib.qd_uniform_f32(x.data_ptr(), q.data_ptr(), n, 0 if bucket_size is None else bucket_size, int(s),
+                                      ab[0].data_ptr(), ab[1].data_ptr(), lev.data_ptr(), None, 0, 0.0, 0, 0,
+                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        _lib.check(lib.qd_pack_levels_u8(lev.data_ptr(), n, bits, packed.data_ptr(), _lib.stream_ptr()))
     return PackedUniform(packed, ab[0], ab[1], tensor.shape, int(s), bucket_size, bits)
 
 
@@ -66,6 +88,9 @@ def histogram_u8(idx, k):
     if idx.dtype != torch.uint8 or not idx.is_cuda:
         raise TypeError('histogram_u8 needs a uint8 tensor on a HIP device')
     idx = idx.contiguous()
+    if _lib.on_other_device(idx):
+        with torch.cuda.device(idx.device):
+            return histogram_u8(idx, k)
     hist = torch.empty(k, dtype=torch.int64, device=idx.device)
     ws = _lib.workspace(idx.device)
     _lib.check(_lib.load().qd_histogram_u8_ws(idx.data_ptr(), idx.numel(), int(k), hist.data_ptr(), ws.data_ptr(), ws.numel(),

@@ -155,6 +155,103 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, float* y,
     }
 }
 
+// uint8 level indices -> packed bits (any bucket geometry: the levels come from qd_uniform_f32's level_idx output).
+// Every thread produces one 32-bit word = 32 / BITS levels; the last, partial word byte by byte.
+template <int BITS>
+__global__ __launch_bounds__(256) void k_pack_levels(const uint8_t* lev, int64_t n, uint8_t* packed) {
+    constexpr int L = 32 / BITS;                     // levels per 32-bit word
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nwords = n / L;
+    const bool vec = ((((uintptr_t)lev) & (L < 16 ? L - 1 : 15)) == 0) && ((((uintptr_t)packed) & 3) == 0);
+    for (int64_t w = tid; w < nwords; w += nth) {
+        const uint8_t* src = lev + w * L;
+        uint32_t word = 0;
+        if (vec) {
+            uint32_t in[L / 4];
+            if (L == 4) in[0] = *(const uint32_t*)src;
+            else if (L == 8) { const uint2 t = *(const uint2*)src; in[0] = t.x; in[1] = t.y; }
+            else {
+#pragma unroll
+                for (int q = 0; q < L / 16; ++q) {
+                    const uint4 t = *(const uint4*)(src + 16 * q);
+                    in[4 * q] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < L; ++c) word |= ((in[c >> 2] >> (8 * (c & 3))) & MASK) << (c * BITS);
+            *(uint32_t*)(packed + 4 * w) = word;
+        } else {
+#pragma unroll
+            for (int c = 0; c < L; ++c) word |= ((uint32_t)src[c] & MASK) << (c * BITS);
+            packed[4 * w] = (uint8_t)word; packed[4 * w + 1] = (uint8_t)(word >> 8);
+            packed[4 * w + 2] = (uint8_t)(word >> 16); packed[4 * w + 3] = (uint8_t)(word >> 24);
+        }
+    }
+    if (tid == 0) {                                  // the levels after the last whole word
+        constexpr int EPB = 8 / BITS;
+        const int64_t e0 = nwords * L;
+        for (int64_t e = e0; e < n; e += EPB) {
+            uint32_t byte = 0;
+            for (int c = 0; c < EPB && e + c < n; ++c) byte |= ((uint32_t)lev[e + c] & MASK) << (c * BITS);
+            packed[(e * BITS) >> 3] = (uint8_t)byte;
+        }
+    }
+}
+
+// decode for ANY bucket size (bucket == 0: one alpha / beta for the tensor): as k_unpack, the bucket of every element from
+// one 32- or 64-bit division per group of four
+template <int BITS>
+__global__ __launch_bounds__(256) void k_unpack_any(const uint8_t* packed, float* y, const float* alpha, const float* beta,
+                                                    int64_t n, int64_t bucket, float sm1) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const int64_t ngroups = (n + 3) >> 2;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const bool y_vec = (((uintptr_t)y) & 15) == 0;
+    const bool small = n < ((int64_t)1 << 32);
+    for (int64_t gI = tid; gI < ngroups; gI += nth) {
+        const int64_t e0 = gI << 2;
+        int64_t bkt = 0, rem = e0;
+        if (bucket > 0) {
+            if (small) { bkt = (uint32_t)e0 / (uint32_t)bucket; rem = e0 - bkt * bucket; }
+            else { bkt = e0 / bucket; rem = e0 - bkt * bucket; }
+        }
+        uint32_t bits;
+        const bool full = e0 + 4 <= n;
+        if (BITS == 8) {
+            if (full) bits = *(const uint32_t*)(packed + e0);
+            else { bits = 0; for (int64_t c = 0; e0 + c < n; ++c) bits |= (uint32_t)packed[e0 + c] << (8 * c); }
+        } else if (BITS == 4) {
+            if (full) bits = *(const uint16_t*)(packed + (e0 >> 1));
+            else { bits = packed[e0 >> 1]; if (e0 + 2 < n) bits |= (uint32_t)packed[(e0 >> 1) + 1] << 8; }
+        } else if (BITS == 2) {
+            bits = packed[e0 >> 2];
+        } else {
+            bits = (uint32_t)packed[e0 >> 3] >> (e0 & 4);
+        }
+        float out[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int64_t bc = bkt;
+            if (bucket > 0 && rem + c >= bucket) bc = bkt + (rem + c) / bucket;   // a group may straddle buckets (bucket < 4: several)
+            const float a = alpha[bc], b = beta[bc];
+            const float r = (float)((bits >> (c * BITS)) & MASK);
+            float w = r / sm1;                         // same three ops as the tail of qdq()
+            float v = w * a;
+            v = v + b;
+            out[c] = v + 0.0f;
+        }
+        if (full && y_vec) {
+            f4 o = {out[0], out[1], out[2], out[3]};
+            __builtin_nontemporal_store(o, (f4*)(y + e0));
+        } else {
+            for (int c = 0; c < 4 && e0 + c < n; ++c) y[e0 + c] = out[c];
+        }
+    }
+}
+
 // histogram of uint8 symbols, any k <= 256, with INTEGER LDS atomics (ds_add_u32 without return) on a [k + 1][32]
 // table shared by the block: column = lane mod 32, so the 32 lanes the LDS serves per cycle hit 32 different banks
 // whatever their symbols are, and two lanes (or waves) that meet on one counter are resolved by the LDS itself -- no
@@ -300,14 +397,39 @@ int qd_pack_uniform_f32(const float* x, int64_t n, int64_t bucket, int levels, i
     return (int)hipGetLastError();
 }
 
+int qd_pack_levels_u8(const uint8_t* levels_idx, int64_t n, int bits, uint8_t* packed, void* stream) {
+    if (n < 0 || (bits != 1 && bits != 2 && bits != 4 && bits != 8) || (n > 0 && (!levels_idx || !packed)))
+        return QD_ERR_INVALID_ARGUMENT;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = blocks_for(n / (32 / bits) + 1, 256 * 4, 1 << 20);
+    if (bits == 8) hipLaunchKernelGGL(k_pack_levels<8>, dim3(blocks), dim3(256), 0, st, levels_idx, n, packed);
+    else if (bits == 4) hipLaunchKernelGGL(k_pack_levels<4>, dim3(blocks), dim3(256), 0, st, levels_idx, n, packed);
+    else if (bits == 2) hipLaunchKernelGGL(k_pack_levels<2>, dim3(blocks), dim3(256), 0, st, levels_idx, n, packed);
+    else hipLaunchKernelGGL(k_pack_levels<1>, dim3(blocks), dim3(256), 0, st, levels_idx, n, packed);
+    return (int)hipGetLastError();
+}
+
 int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int levels, int bits, const float* alpha,
                           const float* beta, float* y, void* stream) {
     if (n < 0 || levels < 2 || (bits != 1 && bits != 2 && bits != 4 && bits != 8) || levels > (1 << bits))
         return QD_ERR_INVALID_ARGUMENT;
     if (n > 0 && (!packed || !y || !alpha || !beta)) return QD_ERR_INVALID_ARGUMENT;
-    if (bucket < 8 || (bucket & (bucket - 1))) return QD_ERR_UNSUPPORTED;
+    if (bucket < 0) return QD_ERR_INVALID_ARGUMENT;
     if ((((uintptr_t)packed) & 3)) return QD_ERR_UNSUPPORTED;
     if (n == 0) return 0;
+    if (bucket < 8 || (bucket & (bucket - 1)) || n < bucket) {
+        // any other bucket size; 0 (or a tensor shorter than one bucket) = one alpha / beta for the whole tensor
+        hipStream_t st2 = (hipStream_t)stream;
+        const float sm1b = (float)(levels - 1);
+        const int64_t bk = (bucket == 0 || n < bucket) ? 0 : bucket;
+        const int blocks2 = blocks_for((n + 3) / 4, 256 * 4, 1 << 20);
+        if (bits == 8) hipLaunchKernelGGL(k_unpack_any<8>, dim3(blocks2), dim3(256), 0, st2, packed, y, alpha, beta, n, bk, sm1b);
+        else if (bits == 4) hipLaunchKernelGGL(k_unpack_any<4>, dim3(blocks2), dim3(256), 0, st2, packed, y, alpha, beta, n, bk, sm1b);
+        else if (bits == 2) hipLaunchKernelGGL(k_unpack_any<2>, dim3(blocks2), dim3(256), 0, st2, packed, y, alpha, beta, n, bk, sm1b);
+        else hipLaunchKernelGGL(k_unpack_any<1>, dim3(blocks2), dim3(256), 0, st2, packed, y, alpha, beta, n, bk, sm1b);
+        return (int)hipGetLastError();
+    }
     int row_shift = 0;
     while (((int64_t)1 << row_shift) < bucket) ++row_shift;
     hipStream_t st = (hipStream_t)stream;

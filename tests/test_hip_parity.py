@@ -548,7 +548,9 @@ def test_beyond_int32_elements():
 def test_pack_unpack_roundtrip(s, bits):
     from quantized_distillation_amd import codec
     rng = np.random.RandomState(s)
-    for n, bucket in [(256 * 40, 256), (100003, 256), (70001, 64), (5 * 2048 + 7, 2048), (300, 256), (1 << 22, 512)]:
+    for n, bucket in [(256 * 40, 256), (100003, 256), (70001, 64), (5 * 2048 + 7, 2048), (300, 256), (1 << 22, 512),
+                      (100003, 100), (100003, 33), (70001, 1000), (1 << 20, 513), (100003, None), (777, None), (5000, 3),
+                      (100003, 4096), (50, 256)]:      # any bucket size: quantize with level indices + pack them
         x = rng.randn(n).astype(np.float32)
         xd = dev(x)
         pk = codec.pack_uniform(xd, s, bucket, bits=bits)
@@ -568,7 +570,7 @@ def test_pack_unpack_roundtrip(s, bits):
         q, _ = quantization.uniformQuantization(xd, s, bucket_size=bucket)
         assert torch.equal(y, q) and np.array_equal(host(y), ref['q'])
         # size = what helpers/functions.py:255-259 charges: bits*N/8 + 8 bytes per bucket
-        assert pk.nbytes == (n * bits + 7) // 8 + 8 * (-(-n // bucket))
+        assert pk.nbytes == (n * bits + 7) // 8 + 8 * (1 if (bucket is None or n < bucket) else -(-n // bucket))
 
 
 def test_level_histogram_and_device_huffman(golden_misc):

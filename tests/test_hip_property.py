@@ -92,7 +92,8 @@ def test_nonuniform_matches_oracle(n, bucket, k, seed, kind, dup):
 
 
 @settings(max_examples=30 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
-@given(n=sizes, bucket=st.sampled_from([64, 128, 256, 512, 1024, 2048]), sb=st.sampled_from([(2, 1), (3, 2), (4, 2), (9, 4), (16, 4), (16, 8), (256, 8)]),
+@given(n=sizes, bucket=st.sampled_from([64, 128, 256, 256, 512, 1024, 2048, None, 100, 33, 7, 3, 1000, 513, 4096, 5003]),
+       sb=st.sampled_from([(2, 1), (3, 2), (4, 2), (9, 4), (16, 4), (16, 8), (256, 8)]),
        seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 5))
 def test_pack_unpack_matches_quantizer(n, bucket, sb, seed, kind):
     from quantized_distillation_amd import codec
