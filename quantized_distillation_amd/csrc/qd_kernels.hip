@@ -830,12 +830,19 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
 // group, as the kernels above do for their 256-element buckets, costs 60-130 us at bucket sizes of 3000-8000.  The chunk
 // kernels above stay for small buckets, where a wave per bucket would leave most lanes idle.  The float4 grid is aligned in ELEMENT index (the base pointer is 16-byte aligned), so the
 // stochastic draw of element e -- Philox block e >> 2, word e & 3 -- is the one every other kernel uses.
-template <int MODE, int V>
+// G = waves per bucket (1, 2 or 4 of the block's four): above 2048 elements a single wave would need more than 8 rounds --
+// 115-252 VGPRs, two to four waves per SIMD -- so the bucket is spread over 2 (up to 4096 elements) or 4 waves (up to
+// 8192), which exchange their (min, max) through LDS across one block barrier; every wave then keeps at most 9 float4s.
+template <int MODE, int V, int G>
 __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
     __shared__ PointTable Ts;
+    __shared__ float red[2][4][2];                         // [iteration parity][wave of the block][min, max]
     const PointTable* T = nullptr;
     if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
-    const int lane = threadIdx.x & 63;
+    constexpr int GL = 64 * G;                             // lanes per bucket
+    constexpr int GPB = 4 / G;                             // buckets per block and iteration
+    const int lane = threadIdx.x & (GL - 1);               // lane inside the bucket's group
+    const int wv = threadIdx.x >> 6;                       // wave of the block
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -843,56 +850,72 @@ __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk,
     const bool prep_on = !prescaled && (p.mean != nullptr || p.me != INFINITY);
     const bool use_tab = MODE == MODE_QDQ && !p.stochastic && p.sm1 <= 15.0f;
     const float tab = (float)(lane & 15) / p.sm1;
-    const int64_t wave = uniform_wave_index();
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t group = (int64_t)blockIdx.x * GPB + (threadIdx.x / GL);
+    const int64_t ngroups = (int64_t)gridDim.x * GPB;
+    const int64_t iters = (nbk + ngroups - 1) / ngroups;   // the same for every wave of the grid: the barriers below are uniform
 
-    for (int64_t bkt = wave; bkt < nbk; bkt += nwaves) {
-        const int64_t lo = bkt * p.row;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t bkt = it * ngroups + group;
+        const bool active = bkt < nbk;                     // uniform over the group's waves
+        const int64_t lo = (active ? bkt : 0) * p.row;
         const int row = (int)(lo + p.row <= p.n ? p.row : p.n - lo);   // the last bucket may be short
         const int64_t a0 = lo & amask;                     // aligned element at or below lo (amask = ~31: a 128-byte line)
         const int off = (int)(a0 - lo);                    // -31 .. 0: position of a0 relative to the bucket
         const int nf = (int)(((lo + row + 3) >> 2) - (a0 >> 2));   // float4s from a0 to the bucket's last one
         const f4* src = (const f4*)(p.x + a0);
         f4 v[V];
+        float a = 1.0f, b = 0.0f;
+        float mn = INFINITY, mx = -INFINITY;
+        if (active) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {                      // always issued, the index clamped (see k_bucket_chunk)
-            const int f = lane + 64 * j;
-            v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
-        }
-        float a, b;
-        if (prescaled) {                                   // x is u, alpha / beta are inputs
-            a = p.alpha[bkt]; b = p.beta[bkt];
-        } else {
-            float mn = INFINITY, mx = -INFINITY;
+            for (int j = 0; j < V; ++j) {                  // always issued, the index clamped (see k_bucket_chunk)
+                const int f = lane + GL * j;
+                v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+            }
+            if (prescaled) {                               // x is u, alpha / beta are inputs
+                a = p.alpha[bkt]; b = p.beta[bkt];
+            } else {
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                if (prep_on) v[j] = prep4(v[j], pp);
-                const int r0 = off + 4 * (lane + 64 * j);  // position of this float4's first element in the bucket
-                if (off + 256 * j >= 0 && off + 256 * (j + 1) <= row) {   // wave-uniform: the whole round is inside
-                    mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j]));
-                } else {
-                    const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                for (int j = 0; j < V; ++j) {
+                    if (prep_on) v[j] = prep4(v[j], pp);
+                    const int r0 = off + 4 * (lane + GL * j);      // position of this float4's first element in the bucket
+                    if (off + 4 * GL * j >= 0 && off + 4 * GL * (j + 1) <= row) {   // group-uniform: the whole round is inside
+                        mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j]));
+                    } else {
+                        const float xs[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const bool in = (unsigned)(r0 + c) < (unsigned)row;
-                        mn = pmin(mn, in ? xs[c] : INFINITY); mx = pmax(mx, in ? xs[c] : -INFINITY);
+                        for (int c = 0; c < 4; ++c) {
+                            const bool in = (unsigned)(r0 + c) < (unsigned)row;
+                            mn = pmin(mn, in ? xs[c] : INFINITY); mx = pmax(mx, in ? xs[c] : -INFINITY);
+                        }
                     }
                 }
+                mn = wave_min(mn); mx = wave_max(mx);
             }
-            mn = wave_min(mn); mx = wave_max(mx);
+        }
+        if (G > 1) {                                       // the bucket's waves exchange (min, max); parity: one barrier per iteration
+            const int par = (int)(it & 1);
+            if ((threadIdx.x & 63) == 0) { red[par][wv][0] = mn; red[par][wv][1] = mx; }
+            __syncthreads();
+            const int w0 = (wv / G) * G;
+#pragma unroll
+            for (int g = 0; g < G; ++g) { mn = pmin(mn, red[par][w0 + g][0]); mx = pmax(mx, red[par][w0 + g][1]); }
+        }
+        if (!active) continue;
+        if (!prescaled) {
             alpha_beta(mn, mx, a, b);
             if (lane == 0) {
                 if (p.alpha) p.alpha[bkt] = a;
                 if (p.beta) p.beta[bkt] = b;
             }
         }
-        const bool fast = MODE == MODE_QDQ && fastdiv_ok(a);   // a is wave-uniform
+        const bool fast = MODE == MODE_QDQ && fastdiv_ok(a);   // a is uniform over the bucket's waves
         auto body = [&](auto fast_c) {
             constexpr bool FAST = decltype(fast_c)::value;
             const float y = FAST ? 1.0f / a : 0.0f;        // RN(1/alpha), one IEEE division per bucket
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const int f = lane + 64 * j;
+                const int f = lane + GL * j;
                 const int r0 = off + 4 * f;
                 const int64_t e = a0 + 4 * (int64_t)f;     // element index of this float4 (a multiple of 4)
                 float side[4], o[4];
@@ -909,7 +932,7 @@ __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk,
                         o[c] = transform<MODE, FAST>(p, T, xs[c], a, b, pp.mean, rnd[c], side[c], y);
                     }
                 }
-                if (off + 256 * j >= 0 && off + 256 * (j + 1) <= row) {    // wave-uniform: the whole round is inside the bucket
+                if (off + 4 * GL * j >= 0 && off + 4 * GL * (j + 1) <= row) {   // group-uniform: the whole round is inside the bucket
                     const f4 r = {o[0], o[1], o[2], o[3]};
                     __builtin_nontemporal_store(r, (f4*)(p.out + e));
                     store_side4_row<MODE>(p, e, side);     // every DPP row holds 16 consecutive float4s, all lanes active
@@ -934,7 +957,7 @@ __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk,
             // element (ref: help_functions.py:76-86)
             float ul = (prep_on ? prep(p.x[p.n - 1], pp) : p.x[p.n - 1]) - b;
             ul = ul / a;
-            for (int64_t i = lo + row + lane; i < lo + p.row; i += 64) p.out[i] = ul;
+            for (int64_t i = lo + row + lane; i < lo + p.row; i += GL) p.out[i] = ul;
         }
     }
 }
@@ -2169,9 +2192,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             case 512: QD_VEC(64, 2, 2)
             case 1024: QD_VEC(64, 4, 1)
             case 2048: QD_VEC(64, 8, 1)
-            case 4096: QD_VEC(64, 16, 1)
-            case 8192: QD_VEC(64, 32, 1)
-            default: break;
+            default: break;       // 4096, 8192: k_bucket_wave_any with two / four waves per bucket (8192: 91.2 vs 95.5 us as 32 float4 per lane)
         }
     }
 #undef QD_VEC
@@ -2190,37 +2211,39 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         // float4s a wave may have to hold: the bucket's own, +1 for a split first/last one, + the lead-in from the boundary
         const int nf_max = (int)(p.row >> 2) + (mult4 ? 0 : 2) + (line_ok ? 0 : al / 4 - 1);
         const int64_t nbk = p.nb;                                                // every bucket, the short last one included
-        if (sel > 0 && nf_max <= 64 * 32 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
-            const int blocks = blocks_for(nbk, 4);
-#define QD_WAVE_ANY(V)                                                                                     \
+        if (sel > 0 && nf_max <= 256 * 9 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
+#define QD_WAVE_ANY(V, G)                                                                                  \
     {                                                                                                      \
-        hipLaunchKernelGGL((k_bucket_wave_any<MODE, V>), dim3(blocks), dim3(256), 0, st, p, nbk, amask);   \
+        const int blocks = blocks_for(nbk, 4 / G);                                                         \
+        hipLaunchKernelGGL((k_bucket_wave_any<MODE, V, G>), dim3(blocks), dim3(256), 0, st, p, nbk, amask); \
         return check_launch();                                                                             \
     }
-            if constexpr (MODE == MODE_QDQ) {              // the hot mode: rounds in steps of one up to 8
-                if (nf_max <= 64 * 2) QD_WAVE_ANY(2)
-                if (nf_max <= 64 * 3) QD_WAVE_ANY(3)
-                if (nf_max <= 64 * 4) QD_WAVE_ANY(4)
-                if (nf_max <= 64 * 5) QD_WAVE_ANY(5)
-                if (nf_max <= 64 * 6) QD_WAVE_ANY(6)
-                if (nf_max <= 64 * 7) QD_WAVE_ANY(7)
-                if (nf_max <= 64 * 8) QD_WAVE_ANY(8)
-                if (nf_max <= 64 * 10) QD_WAVE_ANY(10)
-                if (nf_max <= 64 * 12) QD_WAVE_ANY(12)
-                if (nf_max <= 64 * 14) QD_WAVE_ANY(14)
-                if (nf_max <= 64 * 16) QD_WAVE_ANY(16)
-                if (nf_max <= 64 * 20) QD_WAVE_ANY(20)
-                if (nf_max <= 64 * 24) QD_WAVE_ANY(24)
-                if (nf_max <= 64 * 28) QD_WAVE_ANY(28)
-                QD_WAVE_ANY(32)
+            // one wave per bucket up to 8 rounds (2048 elements), then two (up to 4096) and four waves per bucket
+            if constexpr (MODE == MODE_QDQ) {              // the hot mode: rounds in steps of one
+                if (nf_max <= 64 * 2) QD_WAVE_ANY(2, 1)
+                if (nf_max <= 64 * 3) QD_WAVE_ANY(3, 1)
+                if (nf_max <= 64 * 4) QD_WAVE_ANY(4, 1)
+                if (nf_max <= 64 * 5) QD_WAVE_ANY(5, 1)
+                if (nf_max <= 64 * 6) QD_WAVE_ANY(6, 1)
+                if (nf_max <= 64 * 7) QD_WAVE_ANY(7, 1)
+                if (nf_max <= 64 * 8) QD_WAVE_ANY(8, 1)
+                if (nf_max <= 128 * 5) QD_WAVE_ANY(5, 2)
+                if (nf_max <= 128 * 6) QD_WAVE_ANY(6, 2)
+                if (nf_max <= 128 * 7) QD_WAVE_ANY(7, 2)
+                if (nf_max <= 128 * 8) QD_WAVE_ANY(8, 2)
+                if (nf_max <= 256 * 5) QD_WAVE_ANY(5, 4)
+                if (nf_max <= 256 * 6) QD_WAVE_ANY(6, 4)
+                if (nf_max <= 256 * 7) QD_WAVE_ANY(7, 4)
+                if (nf_max <= 256 * 8) QD_WAVE_ANY(8, 4)
+                QD_WAVE_ANY(9, 4)
             } else {                                       // scale_down, nearest point: fewer instances
-                if (nf_max <= 64 * 3) QD_WAVE_ANY(3)
-                if (nf_max <= 64 * 5) QD_WAVE_ANY(5)
-                if (nf_max <= 64 * 8) QD_WAVE_ANY(8)
-                if (nf_max <= 64 * 12) QD_WAVE_ANY(12)
-                if (nf_max <= 64 * 16) QD_WAVE_ANY(16)
-                if (nf_max <= 64 * 24) QD_WAVE_ANY(24)
-                QD_WAVE_ANY(32)
+                if (nf_max <= 64 * 3) QD_WAVE_ANY(3, 1)
+                if (nf_max <= 64 * 5) QD_WAVE_ANY(5, 1)
+                if (nf_max <= 64 * 8) QD_WAVE_ANY(8, 1)
+                if (nf_max <= 128 * 6) QD_WAVE_ANY(6, 2)
+                if (nf_max <= 128 * 8) QD_WAVE_ANY(8, 2)
+                if (nf_max <= 256 * 6) QD_WAVE_ANY(6, 4)
+                QD_WAVE_ANY(9, 4)
             }
 #undef QD_WAVE_ANY
         }
