@@ -83,6 +83,10 @@ def k1s(i):
 
 timeit('K1  uniform 4-bit bucket 256 (API)', k1, 8)
 timeit('K1  uniform 2-bit bucket 256 (API)', k1_2bit, 8)
+if LOG2 == 26:                                     # SURVEY 8d also asks for the decimal size
+    xd = [x[:64000000] for x in xs]
+    timeit('K1  uniform 4-bit bucket 256, N = 64,000,000', lambda i: live.__setitem__(i % R, quantization.uniformQuantization(xd[i % R], 16, bucket_size=256)[0]), 8, n=64000000)
+    del xd
 timeit('K1  uniform 4-bit bucket 256, ragged N = 64Mi+17', lambda i: live.__setitem__(i % R, quantization.uniformQuantization(xr[i % R], 16, bucket_size=256)[0]), 8, n=N + 17)
 del xr
 timeit('K1  uniform 4-bit bucket 256, weight-like 0.05*randn', lambda i: live.__setitem__(i % R, quantization.uniformQuantization(xw[i % R], 16, bucket_size=256)[0]), 8)
