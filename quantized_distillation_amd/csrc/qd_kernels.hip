@@ -35,6 +35,15 @@ enum Mode { MODE_QDQ = 0, MODE_SCALE = 1, MODE_NEAREST = 2 };
 constexpr int kMaxPoints = 1024;        // LDS table of quantization points
 constexpr int kPartialBlocks = 1024;    // stage-1 blocks of every two-stage reduction
 
+// Alignment the 16-byte (float4) global accesses of the single-tensor entry points need from their fp32 data pointers:
+// FOUR bytes.  global_load / global_store_dwordx4 take any dword-aligned address (the HSA queues run in unaligned access
+// mode), and a wave's 1 KiB per instruction covers the same lines either way: a tensor view that starts 4, 8 or 12 bytes
+// into a 16-byte granule runs at the speed of an aligned one (bucket 256, 64 Mi elements: 87.3 us against 85.3 us; 214 us
+// on the scalar two-pass kernels that the 16-byte requirement of round 1 sent it to).  tests/test_hip_parity.py::
+// test_views_at_every_4_byte_offset runs every entry point on such views.  (int64 index outputs and the workspace keep their
+// 16-byte requirement; the multi-tensor tables are built from 256-byte-aligned slots anyway.)
+constexpr uintptr_t kDataAlign = 3;
+
 struct KParams {
     const float* x;      // input [n]
     float* out;          // QDQ/NEAREST: [n]; SCALE: [padded]
@@ -975,7 +984,7 @@ __global__ __launch_bounds__(256) void k_bucket_groups(KParams p) {
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / LANES;
     const int l = threadIdx.x % LANES;
-    const bool vec4 = (p.row & 3) == 0 && (((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) == 0);
+    const bool vec4 = (p.row & 3) == 0 && (((((uintptr_t)p.x) | ((uintptr_t)p.out)) & kDataAlign) == 0);
     for (int64_t bkt = group; bkt < p.nb; bkt += ngroups) {
         const int64_t lo = bkt * p.row;
         const int64_t hi = lo + p.row < p.n ? lo + p.row : p.n;
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_minmax_partial(const float* x, int64_t 
     int nan = 0;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    if ((((uintptr_t)x) & 15) == 0) {
+    if ((((uintptr_t)x) & kDataAlign) == 0) {
         const int64_t n4 = n >> 2;
         const f4* x4 = (const f4*)x;
         for (int64_t i = tid; i < n4; i += nth) {
@@ -1140,7 +1149,7 @@ __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     const bool prescaled = (MODE == MODE_NEAREST && p.prescaled);
     int64_t done = 0;
-    if (((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) == 0) {
+    if (((((uintptr_t)p.x) | ((uintptr_t)p.out)) & kDataAlign) == 0) {
         const int64_t n4 = p.n >> 2;
         const f4* x4 = (const f4*)p.x;
         f4* o4 = (f4*)p.out;
@@ -1417,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_sum_partial(const float* x, int64_t n, 
     double acc = 0.0;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    if ((((uintptr_t)x) & 15) == 0) {
+    if ((((uintptr_t)x) & kDataAlign) == 0) {
         const int64_t n4 = n >> 2;
         const f4* x4 = (const f4*)x;
         for (int64_t i = tid; i < n4; i += nth) {
@@ -1449,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_inv_scale(const float* u, float* y, int
     const float m = mean ? *mean : 0.0f;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    const bool vec = (((((uintptr_t)u) | ((uintptr_t)y)) & 15) == 0) && (nb == 1 || (row & 3) == 0);
+    const bool vec = (((((uintptr_t)u) | ((uintptr_t)y)) & kDataAlign) == 0) && (nb == 1 || (row & 3) == 0);
     int64_t done = 0;
     if (vec) {
         const int64_t n4 = n >> 2;
@@ -1979,7 +1988,7 @@ __global__ __launch_bounds__(256) void k_clamp(float* w, int64_t n, float limit)
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     int64_t done = 0;
-    if ((((uintptr_t)w) & 15) == 0) {
+    if ((((uintptr_t)w) & kDataAlign) == 0) {
         const int64_t n4 = n >> 2;
         for (int64_t i = tid; i < n4; i += nth) {
             f4 v = ((f4*)w)[i];
@@ -2004,7 +2013,7 @@ __global__ __launch_bounds__(256) void k_truncated_ste(const float* w, float* gr
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     int64_t done = 0;
-    if ((((uintptr_t)w | (uintptr_t)grad) & 15) == 0) {
+    if ((((uintptr_t)w | (uintptr_t)grad) & kDataAlign) == 0) {
         const int64_t n4 = n >> 2;
         for (int64_t i = tid; i < n4; i += nth) {
             const f4 v = __builtin_nontemporal_load((const f4*)w + i);
@@ -2169,7 +2178,7 @@ inline int check_launch() {
 // launch the bucketed transform for nb > 1 (or a short single bucket)
 template <int MODE>
 int launch_bucketed(KParams& p, hipStream_t st) {
-    const bool aligned = ((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) == 0 &&
+    const bool aligned = ((((uintptr_t)p.x) | ((uintptr_t)p.out)) & kDataAlign) == 0 &&
                          (MODE != MODE_NEAREST || p.idx == nullptr || p.idx_bytes != 8 || (((uintptr_t)p.idx) & 15) == 0) &&
                          (MODE != MODE_QDQ || p.lev8 == nullptr || (((uintptr_t)p.lev8) & 3) == 0);
     const int64_t nfull = p.n / p.row;                 // leading full buckets
@@ -2342,7 +2351,7 @@ std::atomic<unsigned> next_launch{1};
 template <int MODE>
 int launch_single_fused(KParams& p, hipStream_t st) {
     const int fmode = g_fused_override >= 0 ? g_fused_override : fused_mode();
-    if (fmode == 0 || ((((uintptr_t)p.x) | ((uintptr_t)p.out)) & 15) != 0) return kNotFused;
+    if (fmode == 0 || ((((uintptr_t)p.x) | ((uintptr_t)p.out)) & kDataAlign) != 0) return kNotFused;
     if ((const void*)p.x == (const void*)p.out) return kNotFused;   // in place: a give-up redo would read transformed data
     // a captured launch would bake its barrier slot into the graph, and two replays in flight would share it
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
@@ -2579,7 +2588,7 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     const bool pow2 = nb == 1 || (row & (row - 1)) == 0;
     if (nb > 1 && pow2) while (((int64_t)1 << row_shift) < row) ++row_shift;
     const bool idx_ok = idx_bytes == 8 ? ((((uintptr_t)idx) & 15) == 0) : ((((uintptr_t)idx) & 3) == 0);
-    const bool fast = k <= 512 && pow2 && idx_ok && ((((uintptr_t)g) & 15) == 0) && (nb == 1 || row >= 4);
+    const bool fast = k <= 512 && pow2 && idx_ok && ((((uintptr_t)g) & kDataAlign) == 0) && (nb == 1 || row >= 4);
     if (fast) {
         // k <= 4: register bins; otherwise an LDS table [k][threads] of lane-private columns
         const int threads = k <= 128 ? 256 : (k <= 256 ? 128 : 64);
@@ -2669,7 +2678,7 @@ int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64
     hipStream_t st = (hipStream_t)stream;
     const float sm1 = (float)(levels - 1);
     int64_t first = 0;                                   // buckets [0, first) take the register path
-    const bool aligned = (((((uintptr_t)x) | ((uintptr_t)g) | ((uintptr_t)out)) & 15) == 0) && nb > 1;
+    const bool aligned = (((((uintptr_t)x) | ((uintptr_t)g) | ((uintptr_t)out)) & kDataAlign) == 0) && nb > 1;
     const int64_t nfull = n / row;
 #define QD_STE(LPB, V)                                                                                   \
     {                                                                                                    \

@@ -240,6 +240,69 @@ def test_other_modes_at_chunk_sizes(bucket):
         assert np.all(np.abs(host(gp).astype(np.float64) - want) <= 4e-6 * absum + 1e-30), (bucket, n)
 
 
+@pytest.mark.parametrize('off', [1, 2, 3])
+def test_views_at_every_4_byte_offset(off):
+    """Tensor views that start 4, 8 or 12 bytes into a 16-byte granule (x[1:], x[2:], x[3:] of an allocation) go through the
+    same 16-byte-access kernels as aligned tensors -- the hardware needs dword alignment only -- and give the same bits as
+    the oracle and as the same call on an aligned copy: every kernel family of uniformQuantization (vector, chunk,
+    chunk_any, one-wave-per-bucket, no buckets small / large), stochastic rounding, in place on the misaligned view,
+    scale_down + inverse, nonUniformQuantization, the pre-processed forward + point gradient, the bucket-aware STE, clamp /
+    truncated-STE."""
+    from quantized_distillation_amd import ste
+    import quantization.quant_functions as qf
+    rng = np.random.RandomState(off)
+
+    def view(a):
+        buf = torch.empty(a.size + 8, dtype=torch.float32, device=DEV)
+        v = buf[off:off + a.size]
+        v.copy_(torch.from_numpy(a))
+        assert v.data_ptr() % 16 == 4 * off
+        return v
+
+    for bucket in (256, 64, 1024, 100, 33, 7, 1000, 513, 5000, None):
+        for n in ((70001, 1 << 21) if bucket in (256, None) else (70001,)):
+            x = rng.randn(n).astype(np.float32)
+            g = rng.randn(n).astype(np.float32)
+            xd, xa, gd, ga = view(x), dev(x), view(g), dev(g)
+            assert xa.data_ptr() % 16 == 0
+            tag = (off, bucket, n)
+            q, sf = quantization.uniformQuantization(xd, 16, bucket_size=bucket)
+            r = oc.uniform_quantize(x, 16, bucket)
+            assert np.array_equal(host(q), r['q']), tag
+            assert np.array_equal(host(sf.alpha).reshape(-1), r['alpha']) and np.array_equal(host(sf.idx_min_rows).reshape(-1), r['imin']), tag
+            qf._STOCHASTIC_CALLS[0] = 1000 + n % 97                      # the same draws for both calls
+            qs, _ = quantization.uniformQuantization(xd, 16, bucket_size=bucket, stochastic_rounding=True)
+            qf._STOCHASTIC_CALLS[0] = 1000 + n % 97
+            qs_a, _ = quantization.uniformQuantization(xa, 16, bucket_size=bucket, stochastic_rounding=True)
+            assert torch.equal(qs, qs_a) and not torch.equal(qs, q), tag
+            y = view(x)                                                   # in place on a misaligned view
+            qi, _ = quantization.uniformQuantization(y, 16, bucket_size=bucket, modify_in_place=True)
+            assert qi.data_ptr() == y.data_ptr() and np.array_equal(host(y), r['q']), tag
+            sfn, sfa = (quantization.ScalingFunction('linear', False, False, bucket) for _ in range(2))
+            u, ua = sfn.scale_down(xd), sfa.scale_down(xa)
+            assert torch.equal(u, ua) and np.array_equal(host(u).reshape(-1)[:n], oc.scale_down(x, bucket)['u']), tag
+            assert torch.equal(sfn.inv_scale_down(u), sfa.inv_scale_down(ua)), tag
+            pts = np.sort(rng.rand(8)).astype(np.float32)
+            qn, idx, _ = quantization.nonUniformQuantization(xd, dev(pts), bucket_size=bucket)
+            rn = oc.nonuniform_quantize(x, pts, bucket)
+            assert np.array_equal(host(qn), rn['q']) and np.array_equal(host(idx), rn['idx']), tag
+            fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=xd)
+            fa = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=xa)
+            qm, qma = fn.forward(None, dev(pts)), fa.forward(None, dev(pts))
+            assert torch.equal(qm, qma) and np.array_equal(host(qm), oc.nonuniform_quantize(x, pts, bucket, 'midpoint')['q']), tag
+            gp, gpa = fn.backward(gd)[1], fa.backward(ga)[1]
+            assert torch.allclose(gp, gpa, rtol=1e-5, atol=1e-6 * float(np.abs(g).sum())), tag
+            if bucket is not None:
+                assert torch.equal(ste.ste_bucket_backward(xd, gd, bucket, 16), ste.ste_bucket_backward(xa, ga, bucket, 16)), tag
+    w = rng.randn(50001).astype(np.float32) * 1.5
+    g = rng.randn(50001).astype(np.float32)
+    wd, gd = view(w), view(g)
+    ste.truncated_ste_(gd, wd)
+    assert np.array_equal(host(gd), np.where(np.abs(w) > 1, 0.0, g).astype(np.float32))
+    ste.clamp_(wd)
+    assert np.array_equal(host(wd), np.clip(w, -1, 1))
+
+
 def test_uniform_big_checksums_from_reference(golden_big):
     for c in golden_big:
         if c['op'] != 'uniform':
