@@ -2206,7 +2206,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     }
 #undef QD_VEC
     p.nvec = 0;
-    if (aligned && p.nb > 1 && p.row > 256 && p.row <= 8192) {
+    if (aligned && p.nb > 1 && p.row > 256 && p.row <= 32768) {
         // one wave per bucket, any size (k_bucket_wave_any).  QD_WAVE_ANY=0: off (A/B), 1: sizes above 512 and sizes from 448
         // that are not a multiple of 4 (multiples of 4 up to 512 stay with the chunk kernel: 300 -> 90 us against 127 us here),
         // 2: every size above 256
@@ -2220,7 +2220,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         // float4s a wave may have to hold: the bucket's own, +1 for a split first/last one, + the lead-in from the boundary
         const int nf_max = (int)(p.row >> 2) + (mult4 ? 0 : 2) + (line_ok ? 0 : al / 4 - 1);
         const int64_t nbk = p.nb;                                                // every bucket, the short last one included
-        if (sel > 0 && nf_max <= 256 * 9 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
+        if (sel > 0 && nf_max <= 256 * 32 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
 #define QD_WAVE_ANY(V, G)                                                                                  \
     {                                                                                                      \
         const int blocks = blocks_for(nbk, 4 / G);                                                         \
@@ -2244,7 +2244,13 @@ int launch_bucketed(KParams& p, hipStream_t st) {
                 if (nf_max <= 256 * 6) QD_WAVE_ANY(6, 4)
                 if (nf_max <= 256 * 7) QD_WAVE_ANY(7, 4)
                 if (nf_max <= 256 * 8) QD_WAVE_ANY(8, 4)
-                QD_WAVE_ANY(9, 4)
+                if (nf_max <= 256 * 9) QD_WAVE_ANY(9, 4)
+                // above 8192 elements: more float4s per lane again (8200 / 10000 / 16384 / 20000 took 148 / 182 / 155 / 284 us on
+                // the two-pass kernels below)
+                if (nf_max <= 256 * 12) QD_WAVE_ANY(12, 4)
+                if (nf_max <= 256 * 16) QD_WAVE_ANY(16, 4)
+                if (nf_max <= 256 * 24) QD_WAVE_ANY(24, 4)
+                QD_WAVE_ANY(32, 4)
             } else {                                       // scale_down, nearest point: fewer instances
                 if (nf_max <= 64 * 3) QD_WAVE_ANY(3, 1)
                 if (nf_max <= 64 * 5) QD_WAVE_ANY(5, 1)
@@ -2252,7 +2258,9 @@ int launch_bucketed(KParams& p, hipStream_t st) {
                 if (nf_max <= 128 * 6) QD_WAVE_ANY(6, 2)
                 if (nf_max <= 128 * 8) QD_WAVE_ANY(8, 2)
                 if (nf_max <= 256 * 6) QD_WAVE_ANY(6, 4)
-                QD_WAVE_ANY(9, 4)
+                if (nf_max <= 256 * 9) QD_WAVE_ANY(9, 4)
+                if (nf_max <= 256 * 16) QD_WAVE_ANY(16, 4)
+                QD_WAVE_ANY(32, 4)
             }
 #undef QD_WAVE_ANY
         }

@@ -171,7 +171,7 @@ def test_uniform_chunk_kernels_many_chunks_per_wave(bucket):
 
 
 @pytest.mark.parametrize('bucket', [257, 300, 511, 513, 600, 770, 1000, 1001, 1023, 1500, 2000, 2049, 3000, 4093, 5000, 6145,
-                                    8000, 8190])
+                                    8000, 8190, 8200, 10001, 16384, 20000, 32768, 32769])
 def test_uniform_wave_per_bucket_any_size(bucket):
     """Bucket sizes above 256 that are not one of the vector sizes: one wave per bucket on the aligned float4s that touch
     it (k_bucket_wave_any).  Tensor ends at, just after and well after a bucket boundary (the last buckets go to the tail
@@ -209,7 +209,7 @@ def test_uniform_wave_per_bucket_any_size(bucket):
     assert np.array_equal(host(h), np.bincount(oc.uniform_quantize(x, 16, bucket)['lev'], minlength=16))
 
 
-@pytest.mark.parametrize('bucket', [33, 255, 300, 506, 509, 511, 513, 1000, 1001, 1017, 1023, 2000, 3001, 5000, 8190])
+@pytest.mark.parametrize('bucket', [33, 255, 300, 506, 509, 511, 513, 1000, 1001, 1017, 1023, 2000, 3001, 5000, 8190, 12000, 30000])
 def test_other_modes_at_chunk_sizes(bucket):
     """scale_down and nonUniformQuantization at bucket sizes of the chunk kernels (with and without the lead-in to the
     128-byte line): bit-exact against the C oracle."""
