@@ -835,7 +835,8 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
 // wave-uniform test), and writes whole float4s with one 16-byte store, the up to 3 + 3 elements of the shared edge float4s
 // one by one.  One pass over HBM at any size, the short last bucket included (its final float4 is fetched whole: an
 // aligned 16-byte load that holds a valid element cannot cross a page, the bytes past the tensor are masked like a
-// neighbour's; nothing is ever stored outside the bucket) -- handing the last one or two buckets of a tensor to a 16-lane
+// neighbour's; nothing is ever stored outside the bucket; for a base that is only 4-byte aligned the launcher sends the last
+// bucket of a tensor whose length is not a multiple of 4 to the scalar path) -- handing the last one or two buckets of a tensor to a 16-lane
 // group, as the kernels above do for their 256-element buckets, costs 60-130 us at bucket sizes of 3000-8000.  The chunk
 // kernels above stay for small buckets, where a wave per bucket would leave most lanes idle.  The float4 grid is aligned in ELEMENT index (the base pointer is 16-byte aligned), so the
 // stochastic draw of element e -- Philox block e >> 2, word e & 3 -- is the one every other kernel uses.
@@ -969,6 +970,8 @@ __global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk,
             for (int64_t i = lo + row + lane; i < lo + p.row; i += GL) p.out[i] = ul;
         }
     }
+    // nbk < p.nb only when the launcher keeps the last bucket away from the float4 path (see there): block 0, scalar accesses
+    if (nbk < p.nb && blockIdx.x == 0) tail_buckets<MODE>(p, T, nbk, pp);
 }
 
 // ---- generic path, small/medium rows: one lane group (16 lanes or a wave) per bucket, 256-thread
@@ -2219,7 +2222,12 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         const int64_t amask = ~(int64_t)(al - 1);
         // float4s a wave may have to hold: the bucket's own, +1 for a split first/last one, + the lead-in from the boundary
         const int nf_max = (int)(p.row >> 2) + (mult4 ? 0 : 2) + (line_ok ? 0 : al / 4 - 1);
-        const int64_t nbk = p.nb;                                                // every bucket, the short last one included
+        // every bucket, the short last one included -- its final float4 is fetched whole, which is safe when the base is 16-byte
+        // aligned (an aligned 16-byte load that holds a valid element cannot cross a page).  A view at a 4-byte offset whose
+        // length is not a multiple of 4 could end 4 .. 12 bytes before a page boundary with nothing mapped behind it: its last
+        // bucket goes through the scalar path of block 0 instead.
+        const bool overread_unsafe = ((((uintptr_t)p.x) & 15) != 0) && ((p.n & 3) != 0);
+        const int64_t nbk = overread_unsafe ? p.nb - 1 : p.nb;
         if (sel > 0 && nf_max <= 256 * 32 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
 #define QD_WAVE_ANY(V, G)                                                                                  \
     {                                                                                                      \
