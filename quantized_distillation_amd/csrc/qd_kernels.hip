@@ -844,7 +844,8 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
 // 115-252 VGPRs, two to four waves per SIMD -- so the bucket is spread over 2 (up to 4096 elements) or 4 waves (up to
 // 8192), which exchange their (min, max) through LDS across one block barrier; every wave then keeps at most 9 float4s.
 template <int MODE, int V, int G>
-__global__ __launch_bounds__(256) void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))   // <= 256 VGPRs: the 32-float4 instance must keep two waves per SIMD
+void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
     __shared__ PointTable Ts;
     __shared__ float red[2][4][2];                         // [iteration parity][wave of the block][min, max]
     const PointTable* T = nullptr;
