@@ -58,12 +58,15 @@ const char* qd_error_string(int code);
  * One buffer of this size per stream is enough; contents need no initialisation. */
 size_t qd_workspace_bytes(void);
 
-/* bucket_size=None tensors (one bucket = whole tensor) that fit the chip's register files are processed by ONE
- * launch -- load once, grid-wide barrier on the per-block min/max, transform from registers (8 B/element) -- instead
- * of reduce + fold + apply.  The barrier never blocks: under contention it gives up after 2 ms and one block finishes
- * the tensor from memory.  mode 1 (default) = on, 0 = always the three-launch path, 2 = always give up at the barrier
- * (exercises the contention path on an idle GPU; for tests).  Returns the previous mode; any other value restores
- * the default (environment QD_SINGLE_FUSED=0|1|abandon).  Process-wide, not thread-safe against concurrent launches. */
+/* bucket_size=None tensors (one bucket = whole tensor) of 16 Ki .. 1 Mi elements are processed by ONE launch -- load
+ * once, grid-wide barrier on the per-block min/max, transform from registers (8 B/element) -- instead of reduce + fold +
+ * apply.  The barrier never blocks: under contention a block gives up after 2 ms, folds the min/max of the whole tensor
+ * itself and carries on; it depends on no other block (no departure counters, no "last block").
+ *   mode 1 (default) = on, 0 = always the three-launch path;
+ *   test hooks that reach the give-up path on an idle GPU: 2 = every block gives up at once, 3 = the blocks with
+ *   blockIdx % 7 == 3, 4 = exactly one block (the middle one).
+ * Returns the previous mode; any other value restores the default.  The only switch of this path (no environment
+ * variable).  Process-wide, not thread-safe against concurrent launches. */
 int qd_set_single_fused_mode(int mode);
 
 /* Number of buckets / padded length of the bucket view (help_functions.py:67-94). Host only. */
@@ -244,6 +247,17 @@ int qd_histogram_u8_ws(const uint8_t* idx, int64_t n, int k, uint64_t* hist, voi
 size_t qd_order_stats_workspace_bytes(int m);
 int qd_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int m, float* out, void* workspace,
                        size_t workspace_bytes, void* stream);
+
+/* ---- self test of the bucket-invariant division (csrc/qd_selftest.hip).  The quantize kernels replace the IEEE division
+ * u = (x - beta) / alpha of quantization/quant_functions.py:106-107 by y = RN(1/alpha) once per bucket and two FMAs per
+ * element (qd_common.h: div_alpha<true>), which must give the correctly rounded quotient bit for bit wherever it is used:
+ * alpha in [2^-60, 2^100], n = 0 or n >= 2^-100.  This entry point generates `npairs` adversarial (n, alpha) pairs of
+ * `family` 0 .. 4 on the device (0: the quantizer's own domain, 1: wide exponents, 2: all-ones / near-power-of-two
+ * significands, 3: near-exact quotients around level and half-level values, 4: the edges of the stated ranges), evaluates
+ * the shortcut with the very function the kernels inline and compares it with n / alpha.
+ * result (device, 4 x uint64): pairs tested, mismatches, (n bits << 32 | alpha bits) of one mismatch, pairs skipped
+ * as outside the domain.  tools/div_invariant_check.py, tests/test_hip_parity.py. */
+int qd_selftest_div_invariant(uint64_t seed, int64_t npairs, int family, unsigned long long* result, void* stream);
 
 #ifdef __cplusplus
 }

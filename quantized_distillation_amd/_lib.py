@@ -78,6 +78,7 @@ SIGNATURES = {
     'qd_histogram_u8_ws': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),
     'qd_order_stats_workspace_bytes': (ctypes.c_size_t, [c_int]),
     'qd_order_stats_f32': (c_int, [c_p, i64, c_p, c_int, c_p, c_p, ctypes.c_size_t, c_p]),
+    'qd_selftest_div_invariant': (c_int, [u64, i64, c_int, c_p, c_p]),
 }
 
 

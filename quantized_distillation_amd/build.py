@@ -20,20 +20,73 @@ def hipcc():
     return exe
 
 
-def build_extension(force=False, verbose=False):
-    srcs = [os.path.join(_lib.CSRC, 'qd_kernels.hip'), os.path.join(_lib.CSRC, 'qd_codec.hip'),
-            os.path.join(_lib.CSRC, 'qd_multi_dq.hip'), os.path.join(_lib.CSRC, 'qd_abs.hip'),
-            os.path.join(_lib.CSRC, 'qd_multi_global.hip'), os.path.join(_lib.CSRC, 'qd_select.hip')]
-    deps = srcs + [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h')]
+SOURCES = ['qd_kernels.hip', 'qd_codec.hip', 'qd_multi_dq.hip', 'qd_abs.hip', 'qd_multi_global.hip', 'qd_select.hip',
+           'qd_selftest.hip']
+OBJ_DIR = os.path.join(os.path.dirname(_lib.INCLUDE), 'build', 'obj')              # git-ignored; objects are rebuilt from source when stale
+
+
+def _compile_flags():
+    return [f for f in HIPCC_FLAGS if f != '-shared'] + ['-I', _lib.INCLUDE]
+
+
+def build_extension(force=False, verbose=False, save_temps_dir=None):
+    """One object per .hip file (compiled in parallel, reused while its sources are older), then one link.
+    save_temps_dir: also keep the device assembly of every file there (tests/test_abi.py reads the kernels' register /
+    scratch / LDS metadata from it)."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = [os.path.join(_lib.CSRC, f) for f in SOURCES]
+    hdrs = [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h'), os.path.abspath(__file__)]
     out = _lib.LIB_PATH
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
-    cmd = [hipcc()] + HIPCC_FLAGS + ['-I', _lib.INCLUDE] + srcs + ['-o', out + '.tmp']
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(out + '.tmp', out)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = [os.path.join(OBJ_DIR, os.path.splitext(f)[0] + '.o') for f in SOURCES]
+
+    def stale(target, deps):
+        return force or not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
+
+    def compile_one(pair):
+        src, obj = pair
+        if not stale(obj, [src] + hdrs):
+            return
+        cmd = [hipcc()] + _compile_flags() + ['-c', src, '-o', obj + '.tmp']
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(obj + '.tmp', obj)
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        list(ex.map(compile_one, zip(srcs, objs)))
+    if save_temps_dir is not None:
+        device_assembly(save_temps_dir, verbose=verbose)
+    if stale(out, objs):
+        cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out + '.tmp']
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(out + '.tmp', out)
     return out
+
+
+def device_assembly(out_dir, verbose=False):
+    """gfx950 assembly of every .hip file (hipcc -S --cuda-device-only) under out_dir; returns the .s paths.  Reused while
+    newer than the sources."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(out_dir, exist_ok=True)
+    hdrs = [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h'), os.path.abspath(__file__)]
+
+    def one(f):
+        src = os.path.join(_lib.CSRC, f)
+        dst = os.path.join(out_dir, os.path.splitext(f)[0] + '.s')
+        if os.path.exists(dst) and all(os.path.getmtime(dst) >= os.path.getmtime(d) for d in [src] + hdrs):
+            return dst
+        cmd = [hipcc()] + [x for x in _compile_flags() if x != '-fPIC'] + ['-S', '--cuda-device-only', src, '-o', dst + '.tmp']
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(dst + '.tmp', dst)
+        return dst
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        return list(ex.map(one, SOURCES))
 
 
 def build_glue(force=False, verbose=False):

@@ -833,10 +833,9 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
 // float4 with its neighbours (those two are fetched twice, the second time from L2) -- keeps them in registers, reduces
 // min / max over the elements that belong to the bucket (rounds that lie wholly inside take the unmasked path: a
 // wave-uniform test), and writes whole float4s with one 16-byte store, the up to 3 + 3 elements of the shared edge float4s
-// one by one.  One pass over HBM at any size, the short last bucket included (its final float4 is fetched whole: an
-// aligned 16-byte load that holds a valid element cannot cross a page, the bytes past the tensor are masked like a
-// neighbour's; nothing is ever stored outside the bucket; for a base that is only 4-byte aligned the launcher sends the last
-// bucket of a tensor whose length is not a multiple of 4 to the scalar path) -- handing the last one or two buckets of a tensor to a 16-lane
+// one by one.  One pass over HBM at any size, the short last bucket included (the float4 that would reach past the end of
+// the tensor is fetched as x[n-4 .. n-1] and rotated in registers: no byte outside the tensor is read, and nothing is
+// ever stored outside the bucket) -- handing the last one or two buckets of a tensor to a 16-lane
 // group, as the kernels above do for their 256-element buckets, costs 60-130 us at bucket sizes of 3000-8000.  The chunk
 // kernels above stay for small buckets, where a wave per bucket would leave most lanes idle.  The float4 grid is aligned in ELEMENT index (the base pointer is 16-byte aligned), so the
 // stochastic draw of element e -- Philox block e >> 2, word e & 3 -- is the one every other kernel uses.
@@ -874,6 +873,14 @@ void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
         const int off = (int)(a0 - lo);                    // -31 .. 0: position of a0 relative to the bucket
         const int nf = (int)(((lo + row + 3) >> 2) - (a0 >> 2));   // float4s from a0 to the bucket's last one
         const f4* src = (const f4*)(p.x + a0);
+        // The bucket's last float4 may reach past the END OF THE TENSOR (n % 4 != 0; the last bucket, or the one before it
+        // when the last one has fewer than 3 elements).  The lane that holds it fetches the 16 bytes x[n-4 .. n-1] instead
+        // -- the same instruction with another address: 16-byte accesses need 4-byte alignment only -- and rotates the
+        // t = n % 4 valid elements to the front; nothing outside the tensor is ever read.
+        // (Instances with more than 16 float4 per lane -- buckets above 12288 elements -- sit at the 256-VGPR limit and have
+        // no room for the rotation: the launcher keeps such buckets out of their range, block 0 does them with scalar
+        // accesses below.)
+        const bool tail_partial = V <= 16 && active && (((lo + row + 3) >> 2) << 2) > p.n;      // group-uniform
         f4 v[V];
         float a = 1.0f, b = 0.0f;
         float mn = INFINITY, mx = -INFINITY;
@@ -881,7 +888,23 @@ void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
 #pragma unroll
             for (int j = 0; j < V; ++j) {                  // always issued, the index clamped (see k_bucket_chunk)
                 const int f = lane + GL * j;
-                v[j] = __builtin_nontemporal_load(src + (f < nf ? f : nf - 1));
+                const int fc = f < nf ? f : nf - 1;
+                const float* ptr = (const float*)(src + fc);
+                if (V <= 16 && tail_partial && fc == nf - 1) ptr = p.x + (p.n - 4);
+                v[j] = __builtin_nontemporal_load((const f4*)ptr);
+            }
+            if (V <= 16 && tail_partial) {
+                const int t = (int)(p.n & 3);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const int f = lane + GL * j;
+                    if ((f < nf ? f : nf - 1) == nf - 1) {
+                        const f4 w = v[j];
+                        v[j].x = t == 1 ? w.w : (t == 2 ? w.z : w.y);
+                        v[j].y = t == 2 ? w.w : w.z;
+                        v[j].z = w.w;
+                    }
+                }
             }
             if (prescaled) {                               // x is u, alpha / beta are inputs
                 a = p.alpha[bkt]; b = p.beta[bkt];
@@ -971,8 +994,9 @@ void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
             for (int64_t i = lo + row + lane; i < lo + p.row; i += GL) p.out[i] = ul;
         }
     }
-    // nbk < p.nb only when the launcher keeps the last bucket away from the float4 path (see there): block 0, scalar accesses
-    if (nbk < p.nb && blockIdx.x == 0) tail_buckets<MODE>(p, T, nbk, pp);
+    // nbk < p.nb only for the instances above 16 float4 per lane when the tensor's length is not a multiple of 4 (see the
+    // launcher): the bucket(s) whose last float4 would reach past the end of the tensor, block 0, scalar accesses
+    if (V > 16 && nbk < p.nb && blockIdx.x == 0) tail_buckets<MODE>(p, T, nbk, pp);
 }
 
 // ---- generic path, small/medium rows: one lane group (16 lanes or a wave) per bucket, 256-thread
@@ -1189,10 +1213,9 @@ __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab
 }
 
 // ---- single-bucket path in ONE launch for tensors that fit the register files ------------------
-// k_single_fused: every lane loads its share of the tensor ONCE into registers (V float4 per lane; 768 blocks
-// x 256 lanes x 24 float4 = 75 MB, the chip's VGPR files hold 128 MB), the blocks publish their min/max, meet at
-// a grid-wide barrier, and transform their registers with the folded (alpha, beta): the tensor is read from HBM
-// once and written once (8 B/element instead of 12) in one launch instead of three
+// k_single_fused: every lane loads its share of the tensor ONCE into registers (V float4 per lane), the blocks
+// publish their min/max, meet at a grid-wide barrier, and transform their registers with the folded (alpha, beta):
+// the tensor is read from HBM once and written once (8 B/element instead of 12) in one launch instead of three
 // (ref: quant_functions.py:85-87,95-97 with bucket_size=None).
 //
 // The barrier has NO counter.  Device-scope round trips cost 1-2 us on this chip (the coherence point is behind
@@ -1202,48 +1225,39 @@ __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab
 // slots -- each lane checks G/256 of them, one round trip per sweep -- until every slot carries this epoch; the
 // last sweep IS the fold.  No read-modify-write, no fence, no serialisation.
 //
-// The barrier is also OPTIMISTIC.  A grid barrier needs all blocks resident at the same time; the launch is
-// sized for that (<= occupancy x CUs), but another stream or process may hold part of the GPU, and two such
-// kernels could starve each other forever.  So a block that still misses a slot after 2 ms of the 100 MHz wall
-// clock gives up: it writes nothing and leaves (frees the CU).  Departures are counted (fan-out over 32 lines,
-// fire and forget); the LAST block to leave, seeing that somebody gave up, transforms the whole tensor alone
-// from memory -- every slot is published by then.  Blocks that did pass the barrier have written the same
-// values, so a mixed outcome is harmless; that needs out != x, so in-place calls take the three-launch path.
-// The control block lives in a __device__ array (zero-initialised when the module is loaded, per device and per
-// process; epoch 0 is never used), not in the caller's workspace, whose contents are undefined by contract;
-// the host hands every launch its own slot set (round robin over kFusedSlots, far more than the kernels a
-// process can have executing at once).
+// The barrier is also OPTIMISTIC, and a block that gives up depends on NOBODY.  A grid barrier needs all blocks
+// resident at the same time; the launch is sized for that (<= one block per CU), but another stream or process may
+// hold part of the GPU, and two such kernels could starve each other forever.  So a block that still misses a slot
+// after 2 ms of the 100 MHz wall clock stops waiting and folds the min/max of the WHOLE tensor itself, from memory
+// (at most 1 Mi elements = 4 MiB, served by L2 / the Infinity Cache; x is never written: in-place calls take the
+// three-launch path), then transforms its own registers like everybody else.  min / max do not depend on the fold order,
+// so it arrives at the same (alpha, beta) bit for bit as the blocks that did meet.  There is no departure count, no
+// "last block", no flag that one block sets and another must see: every block's output depends only on x and on slot
+// values it has itself observed with this launch's tag (round 2's protocol -- a relaxed gave_up counter read by the last
+// block out -- could miss a departure and leave a slice unwritten).
+// A slot is two 8-byte words {min bits | epoch low half << 32}, {max bits | epoch high half << 32}; each word is written
+// and read with one atomic access, so a value can never be seen with another launch's tag.  The epoch is a 64-bit host
+// counter that never repeats (a 31-bit one wrapped after 2^31 launches, and slots that only large grids touch could
+// still carry the old tag).  Should two launches ever share a slot set while both are running (more than kFusedSlots
+// of these kernels in flight), they overwrite each other's tags, their sweeps fail, and both take the give-up path:
+// slow, still correct.  The slots live in a __device__ array (zero-initialised when the module is loaded, per device
+// and per process; epoch 0 is never used), not in the caller's workspace, whose contents are undefined by contract.
 constexpr int kFusedSlots = 64;
-constexpr int kFan = 32;
+constexpr int kFusedMaxBlocks = 256;                   // <= one block per CU: every block sweeps all G slots
 constexpr long long kBarrierTimeout = 200000;          // 2 ms of the 100 MHz wall clock
-struct alignas(128) CtlLine { unsigned v; unsigned pad[31]; };
 struct FusedCtl {
-    unsigned long long slot[kPartialBlocks][2];   // {min bits | epoch << 32}, {max bits | epoch << 32}
-    CtlLine depart[kFan];
-    CtlLine top_depart;
-    CtlLine gave_up;
+    unsigned long long slot[kFusedMaxBlocks][2];
 };
 __device__ FusedCtl g_fused_ctl[kFusedSlots];
 
-__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// test hooks of qd_set_single_fused_mode(): which blocks skip the barrier and take the give-up path at once
+enum { FUSED_GIVE_UP_NONE = 0, FUSED_GIVE_UP_ALL = 1, FUSED_GIVE_UP_EVERY_7TH = 2, FUSED_GIVE_UP_ONE = 3 };
+
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// fan-out counter: true for exactly one caller, the one whose count completes its line and then the top word
-__device__ __forceinline__ bool fan_count(CtlLine* lines, CtlLine* top, unsigned block, unsigned G) {
-    const unsigned sub = block % kFan;
-    const unsigned expected = (G - sub + kFan - 1) / kFan;     // blocks with index % kFan == sub
-    const unsigned ntop = G < (unsigned)kFan ? G : (unsigned)kFan;
-    if (atomicAdd(&lines[sub].v, 1u) + 1u != expected) return false;
-    return atomicAdd(&top->v, 1u) + 1u == ntop;
 }
 
 template <int MODE>
@@ -1259,15 +1273,16 @@ __device__ __forceinline__ f4 transform4(const KParams& p, const PointTable* T, 
     return r;
 }
 
-// One sweep over the G slots (all threads of the block): true when every slot carries `epoch`; then (mn, mx) is the
-// fold of all partials (NaN in any of them poisons both, as torch's min/max do).
-__device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, unsigned epoch, float* red, float& mn, float& mx) {
+// One sweep over the G slots (all threads of the block): true when every slot carries this launch's epoch; then
+// (mn, mx) is the fold of all partials (NaN in any of them poisons both, as torch's min/max do).
+__device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, unsigned ep_lo, unsigned ep_hi, float* red,
+                                            float& mn, float& mx) {
     float fmn = INFINITY, fmx = -INFINITY;
     int fnan = 0, missing = 0;
     for (unsigned i = threadIdx.x; i < G; i += blockDim.x) {
         const unsigned long long a = ld_agent(&ctl->slot[i][0]);
         const unsigned long long b = ld_agent(&ctl->slot[i][1]);
-        missing |= ((unsigned)(a >> 32) != epoch) | ((unsigned)(b >> 32) != epoch);
+        missing |= ((unsigned)(a >> 32) != ep_lo) | ((unsigned)(b >> 32) != ep_hi);
         const float pm = __uint_as_float((unsigned)a), px = __uint_as_float((unsigned)b);
         fnan |= (pm != pm);
         fmn = fminf(fmn, pm);
@@ -1280,26 +1295,26 @@ __device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, uns
     return true;
 }
 
-// V float4 per lane at W waves per SIMD: W = 4 gives 128 VGPRs (V <= 16), W = 3 gives 168 (V = 24: 768 resident blocks x
-// 256 lanes x 24 float4 = 75 MB, which covers WideResNet-16-22's largest tensor, 17.8 M elements = 71 MB).
+// V float4 per lane at W waves per SIMD (W = 4: 128 VGPRs).  The launcher uses it up to 1 Mi elements (V <= 4).
 template <int MODE, int V, int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
-void k_single_fused(KParams p, int slot_set, unsigned epoch, int force_give_up) {
+void k_single_fused(KParams p, int slot_set, unsigned ep_lo, unsigned ep_hi, int give_up_mode) {
     __shared__ PointTable Ts;
     __shared__ float red[32];
     __shared__ int s_timed_out;
-    __shared__ int s_last;
     const PointTable* T = nullptr;
     if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
     const unsigned G = gridDim.x;
-    const unsigned ntop = G < (unsigned)kFan ? G : (unsigned)kFan;
     FusedCtl* ctl = &g_fused_ctl[slot_set];
     const int64_t n4 = p.n >> 2;
     const f4* x4 = (const f4*)p.x;
     f4* o4 = (f4*)p.out;
+    const bool forced = give_up_mode == FUSED_GIVE_UP_ALL ||
+                        (give_up_mode == FUSED_GIVE_UP_EVERY_7TH && blockIdx.x % 7 == 3) ||
+                        (give_up_mode == FUSED_GIVE_UP_ONE && blockIdx.x == G / 2);
 
     // ---- load once, reduce ----
     f4 v[V];
@@ -1327,101 +1342,77 @@ void k_single_fused(KParams p, int slot_set, unsigned epoch, int force_give_up) 
     block_minmax(mn, mx, red);
     if (__syncthreads_or(nan)) { mn = NAN; mx = NAN; }      // NaN poisons the partial, hence the tensor
 
-    // ---- publish ----
+    // ---- publish (also by a block that is about to give up: the others must not wait for it) ----
     if (threadIdx.x == 0) {
-        st_agent(&ctl->slot[blockIdx.x][0], (unsigned long long)__float_as_uint(mn) | ((unsigned long long)epoch << 32));
-        st_agent(&ctl->slot[blockIdx.x][1], (unsigned long long)__float_as_uint(mx) | ((unsigned long long)epoch << 32));
-        s_timed_out = force_give_up;
+        st_agent(&ctl->slot[blockIdx.x][0], (unsigned long long)__float_as_uint(mn) | ((unsigned long long)ep_lo << 32));
+        st_agent(&ctl->slot[blockIdx.x][1], (unsigned long long)__float_as_uint(mx) | ((unsigned long long)ep_hi << 32));
+        s_timed_out = forced ? 1 : 0;
     }
     __syncthreads();
 
     // ---- meet: sweep the slots until all carry this epoch (the successful sweep is the fold) ----
-    bool fast = false;
-    if (!force_give_up) {
+    bool met = false;
+    if (!forced) {
         const long long t0 = wall_clock64();
         for (;;) {
-            if (sweep_slots(ctl, G, epoch, red, mn, mx)) { fast = true; break; }
+            if (sweep_slots(ctl, G, ep_lo, ep_hi, red, mn, mx)) { met = true; break; }
             if (threadIdx.x == 0 && wall_clock64() - t0 > kBarrierTimeout) s_timed_out = 1;
             __syncthreads();
             if (s_timed_out) break;
             __builtin_amdgcn_s_sleep(4);
         }
     }
-
-    float a = 1.0f, b = 0.0f;
-    if (fast) {
-        alpha_beta(mn, mx, a, b);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (p.alpha) p.alpha[0] = a;
-            if (p.beta) p.beta[0] = b;
-        }
-        // ---- transform the registers ----
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const int64_t i = ((int64_t)j * G + blockIdx.x) * 256 + threadIdx.x;
-            if (i < n4) {
-                float side[4];
-                const f4 r = transform4<MODE>(p, T, v[j], a, b, pp.mean, i, side);
-                stg_nt(r, o4 + i);
-                store_side4<MODE>(p, i << 2, side);
-            }
-        }
-        if (owns_tail)
-            for (int t = 0; t < ntail; ++t) {
-                const int64_t e = (n4 << 2) + t;
-                float rnd = 0.0f;
-                if (MODE == MODE_QDQ && p.stochastic) {
-                    float r4[4];
-                    philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
-                    rnd = r4[e & 3];
-                }
-                float side = 0.0f;
-                p.out[e] = transform<MODE>(p, T, tail[t], a, b, pp.mean, rnd, side);
-                store_side1<MODE>(p, e, side);
-            }
-    }
-
-    // ---- leave; the last block out cleans up after anybody who gave up ----
-    if (threadIdx.x == 0) {
-        if (!fast) atomicAdd(&ctl->gave_up.v, 1u);
-        s_last = fan_count(ctl->depart, &ctl->top_depart, blockIdx.x, G) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const bool redo = ld_agent(&ctl->gave_up.v) != 0u;     // every departure (and its gave_up increment) precedes this read
-    if (redo) {
-        // every block has published by now, so one sweep succeeds; then this block alone, from memory (x is intact)
-        while (!sweep_slots(ctl, G, epoch, red, mn, mx)) __builtin_amdgcn_s_sleep(4);
-        alpha_beta(mn, mx, a, b);
-        if (threadIdx.x == 0) {
-            if (p.alpha) p.alpha[0] = a;
-            if (p.beta) p.beta[0] = b;
-        }
+    if (!met) {
+        // ---- gave up: this block folds the whole tensor alone (same min / max, whatever the order) ----
+        float gmn = INFINITY, gmx = -INFINITY;
+        int gnan = 0;
         for (int64_t i = threadIdx.x; i < n4; i += 256) {
-            float side[4];
-            const f4 r = transform4<MODE>(p, T, prep4(x4[i], pp), a, b, pp.mean, i, side);
-            o4[i] = r;
-            store_side4<MODE>(p, i << 2, side);
+            const f4 t = prep4(x4[i], pp);
+            gmn = fminf(gmn, fminf(fminf(t.x, t.y), fminf(t.z, t.w)));
+            gmx = fmaxf(gmx, fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+            gnan |= has_nan4(t);
         }
         if (threadIdx.x == 0)
             for (int t = 0; t < ntail; ++t) {
-                const int64_t e = (n4 << 2) + t;
-                float rnd = 0.0f;
-                if (MODE == MODE_QDQ && p.stochastic) {
-                    float r4[4];
-                    philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
-                    rnd = r4[e & 3];
-                }
-                float side = 0.0f;
-                p.out[e] = transform<MODE>(p, T, prep(p.x[e], pp), a, b, pp.mean, rnd, side);
-                store_side1<MODE>(p, e, side);
+                const float e = prep(p.x[(n4 << 2) + t], pp);
+                gmn = fminf(gmn, e); gmx = fmaxf(gmx, e);
+                gnan |= (e != e);
             }
+        block_minmax(gmn, gmx, red);
+        if (__syncthreads_or(gnan)) { gmn = NAN; gmx = NAN; }
+        mn = gmn; mx = gmx;
     }
-    if (threadIdx.x == 0) {                                    // everybody has left: re-arm the counters
-        for (unsigned i = 0; i < ntop; ++i) st_agent(&ctl->depart[i].v, 0u);
-        st_agent(&ctl->gave_up.v, 0u);
-        __hip_atomic_store(&ctl->top_depart.v, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+
+    float a, b;
+    alpha_beta(mn, mx, a, b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (p.alpha) p.alpha[0] = a;
+        if (p.beta) p.beta[0] = b;
     }
+    // ---- transform the registers ----
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int64_t i = ((int64_t)j * G + blockIdx.x) * 256 + threadIdx.x;
+        if (i < n4) {
+            float side[4];
+            const f4 r = transform4<MODE>(p, T, v[j], a, b, pp.mean, i, side);
+            stg_nt(r, o4 + i);
+            store_side4<MODE>(p, i << 2, side);
+        }
+    }
+    if (owns_tail)
+        for (int t = 0; t < ntail; ++t) {
+            const int64_t e = (n4 << 2) + t;
+            float rnd = 0.0f;
+            if (MODE == MODE_QDQ && p.stochastic) {
+                float r4[4];
+                philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
+                rnd = r4[e & 3];
+            }
+            float side = 0.0f;
+            p.out[e] = transform<MODE>(p, T, tail[t], a, b, pp.mean, rnd, side);
+            store_side1<MODE>(p, e, side);
+        }
 }
 
 // ---- mean (float64 accumulation, fixed order) -------------------------------------------------
@@ -1815,28 +1806,67 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
     }
 }
 
-// stage 1 (generic path): any alignment / bucket size / k <= 1024; LDS table bins[k][C] with
-// atomics (lanes that share a column and an index collide; correct, order of those not fixed).
-__global__ __launch_bounds__(256) void k_point_grad_generic(const float* g, const void* idx, int idx_bytes,
-                                                            const float* alpha, int64_t n, int64_t row, int64_t nb,
-                                                            int k, int C, float* part /* [grid][k] */) {
+// stage 1 (any alignment, any bucket size, k <= 1024): scalar accesses, the bucket of an element advanced
+// incrementally (no division in the loop), and the same lane-private columns as the fast path -- bins[k][C] in LDS,
+// plain read-add-write, NO atomics (round 2 used ds_add_f32 here, whose order is not fixed: the result changed from run
+// to run).  C = 256 columns for 256-lane blocks while the table fits 64 KiB (k <= 64); above that one WAVE per block
+// with 64 columns (k <= 512, up to 128 KiB) or 32 columns that the two halves of the wave update one after the other
+// (k <= 1024: LDS operations of one wave complete in order, the wave barrier only pins the compiler).  Fixed per-lane
+// order, fixed fold order: deterministic.
+template <int IDXB>
+__global__ void k_point_grad_any(const float* g, const void* idx, const float* alpha, int64_t n, int64_t row, int64_t nb,
+                                 int k, int C, float* part /* [grid][k] */) {
     extern __shared__ __attribute__((aligned(16))) float bins[];        // [k][C]
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    for (int j = threadIdx.x; j < k * C; j += blockDim.x) bins[j] = 0.0f;
+    const int T = blockDim.x;                                           // 256 (C == 256) or 64 (C == 64 / 32)
+    for (int j = threadIdx.x; j < k * C; j += T) bins[j] = 0.0f;
     __syncthreads();
     float* col = bins + (threadIdx.x % C);
-    const bool small = n < (int64_t)0xFFFFFFFFll;
-    for (int64_t i = tid; i < n; i += nth) {
-        const int64_t bkt = nb == 1 ? 0 : (small ? (int64_t)((uint32_t)i / (uint32_t)row) : i / row);
-        const float m = g[i] * alpha[bkt];
-        const int id = idx_bytes == 8 ? (int)((const int64_t*)idx)[i] : (int)((const uint8_t*)idx)[i];
-        atomicAdd(col + id * C, m);
+    const int half = threadIdx.x / C;                                   // 0, or 1 for the upper half-wave when C == 32
+    const bool two_phases = C < T;
+    const int64_t tid = (int64_t)blockIdx.x * T + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * T;
+    // bucket of element i = tid + j * nth, advanced by (nth / row, nth % row) per step
+    int64_t bkt = nb == 1 ? 0 : tid / row;
+    int64_t rem = nb == 1 ? 0 : tid % row;
+    const int64_t dq = nb == 1 ? 0 : nth / row, dr = nb == 1 ? 0 : nth % row;
+    constexpr int U = 4;                                                 // loads in flight per lane
+    const int64_t rounds = (n + nth * U - 1) / (nth * U);               // uniform over the grid: the phases below need whole waves
+    int64_t i = tid;
+    for (int64_t r = 0; r < rounds; ++r) {
+        float m[U];
+        int id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = i < n;
+            const int64_t ic = live ? i : 0;
+            const float gv = g[ic];
+            const float av = alpha[live ? bkt : 0];
+            const int ii = IDXB == 8 ? (int)((const int64_t*)idx)[ic] : (int)((const uint8_t*)idx)[ic];
+            m[u] = live ? gv * av : 0.0f;                               // one fp32 multiply, :495; a dead lane adds +0 to bin 0
+            id[u] = live ? ii : 0;
+            i += nth;
+            bkt += dq; rem += dr;
+            if (rem >= row) { rem -= row; ++bkt; }
+        }
+        __builtin_amdgcn_sched_barrier(0);                              // all loads issued before the first table update
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!two_phases) {
+                col[id[u] * C] += m[u];
+            } else {
+                if (half == 0) col[id[u] * C] += m[u];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (half == 1) col[id[u] * C] += m[u];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    for (int j = threadIdx.x; j < k; j += T) {                          // fixed order over the columns, rotated start
         float acc = 0.0f;
-        for (int c = 0; c < C; ++c) acc += bins[j * C + ((c + j) % C)];
+        for (int c = 0; c < C; ++c) acc += bins[j * C + ((c + j) & (C - 1))];
         part[(int64_t)blockIdx.x * k + j] = acc;
     }
 }
@@ -2195,9 +2225,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V, U>), dim3(blocks), dim3(256), 0, st, p); \
         return check_launch();                                                                  \
     }
-    static int no_vec = -1;
-    if (no_vec < 0) { const char* e = getenv("QD_NO_VEC"); no_vec = e ? atoi(e) : 0; }   // A/B: large vector sizes through k_bucket_wave_any
-    if (aligned && p.nb > 1 && !(no_vec && p.row > 256)) {
+    if (aligned && p.nb > 1) {
         switch (p.row) {
             case 64: QD_VEC(16, 1, 4)
             case 128: QD_VEC(16, 2, 2)
@@ -2211,28 +2239,26 @@ int launch_bucketed(KParams& p, hipStream_t st) {
 #undef QD_VEC
     p.nvec = 0;
     if (aligned && p.nb > 1 && p.row > 256 && p.row <= 32768) {
-        // one wave per bucket, any size (k_bucket_wave_any).  QD_WAVE_ANY=0: off (A/B), 1: sizes above 512 and sizes from 448
-        // that are not a multiple of 4 (multiples of 4 up to 512 stay with the chunk kernel: 300 -> 90 us against 127 us here),
-        // 2: every size above 256
-        static int sel = -1;
-        if (sel < 0) { const char* e = getenv("QD_WAVE_ANY"); sel = e ? atoi(e) : 1; }
+        // one wave per bucket, any size (k_bucket_wave_any): sizes above 512, and sizes from 448 that are not a multiple of 4
+        // (multiples of 4 up to 512 stay with the chunk kernel: 300 -> 90 us against 127 us here; the vector sizes 512 /
+        // 1024 / 2048 were taken above).  The lane -> float4 mapping starts at the 128-byte line (32 elements) at or below
+        // the bucket (measured against 16- and 64-element boundaries: profiles/r02_tune_kernels.txt).
         const bool mult4 = (p.row & 3) == 0;
-        static int al = -1;
-        if (al < 0) { const char* e = getenv("QD_WAVE_ALIGN"); al = e ? atoi(e) : 32; if (al != 4 && al != 16 && al != 32 && al != 64) al = 32; }
+        constexpr int al = 32;
         const bool line_ok = (p.row * 4) % (al * 4) == 0;                        // every bucket starts on the boundary anyway
         const int64_t amask = ~(int64_t)(al - 1);
         // float4s a wave may have to hold: the bucket's own, +1 for a split first/last one, + the lead-in from the boundary
         const int nf_max = (int)(p.row >> 2) + (mult4 ? 0 : 2) + (line_ok ? 0 : al / 4 - 1);
-        // every bucket, the short last one included -- its final float4 is fetched whole, which is safe when the base is 16-byte
-        // aligned (an aligned 16-byte load that holds a valid element cannot cross a page).  A view at a 4-byte offset whose
-        // length is not a multiple of 4 could end 4 .. 12 bytes before a page boundary with nothing mapped behind it: its last
-        // bucket goes through the scalar path of block 0 instead.
-        const bool overread_unsafe = ((((uintptr_t)p.x) & 15) != 0) && ((p.n & 3) != 0);
-        const int64_t nbk = overread_unsafe ? p.nb - 1 : p.nb;
-        if (sel > 0 && nf_max <= 256 * 32 && (sel >= 2 || p.row > 512 || (!mult4 && p.row >= 448))) {
+        // every bucket, the short last one included (the float4 that would reach past the end of the tensor is fetched as
+        // x[n-4 .. n-1] and rotated: nothing outside the tensor is read, whatever the alignment of the base)
+        // (the two largest instances have no registers to spare for that and leave those buckets to block 0's scalar path)
+        int64_t nbk_all = p.nb, nbk_whole = p.nb;
+        while (nbk_whole > 0 && ((((nbk_whole * p.row < p.n ? nbk_whole * p.row : p.n) + 3) >> 2) << 2) > p.n) --nbk_whole;
+        if (nf_max <= 256 * 32 && (p.row > 512 || (!mult4 && p.row >= 448))) {
 #define QD_WAVE_ANY(V, G)                                                                                  \
     {                                                                                                      \
-        const int blocks = blocks_for(nbk, 4 / G);                                                         \
+        const int64_t nbk = V > 16 ? nbk_whole : nbk_all;                                                  \
+        const int blocks = blocks_for(nbk > 0 ? nbk : 1, 4 / G);                                           \
         hipLaunchKernelGGL((k_bucket_wave_any<MODE, V, G>), dim3(blocks), dim3(256), 0, st, p, nbk, amask); \
         return check_launch();                                                                             \
     }
@@ -2268,8 +2294,13 @@ int launch_bucketed(KParams& p, hipStream_t st) {
                 if (nf_max <= 128 * 8) QD_WAVE_ANY(8, 2)
                 if (nf_max <= 256 * 6) QD_WAVE_ANY(6, 4)
                 if (nf_max <= 256 * 9) QD_WAVE_ANY(9, 4)
-                if (nf_max <= 256 * 16) QD_WAVE_ANY(16, 4)
-                QD_WAVE_ANY(32, 4)
+                // more float4s per lane: scale_down only -- the point search of the nearest-point mode keeps too much live
+                // and the compiler demotes the float4 array to scratch memory (272 / 528 bytes per lane); buckets above 9216
+                // elements take the two-pass kernels below in that mode
+                if constexpr (MODE == MODE_SCALE) {
+                    if (nf_max <= 256 * 16) QD_WAVE_ANY(16, 4)
+                    QD_WAVE_ANY(32, 4)
+                }
             }
 #undef QD_WAVE_ANY
         }
@@ -2336,17 +2367,10 @@ int launch_bucketed(KParams& p, hipStream_t st) {
 
 // one-launch single bucket (k_single_fused) when the tensor fits the register files of a resident grid
 constexpr int kNotFused = -1000;
-// QD_SINGLE_FUSED=0: always the three-launch path (A/B measurements); =abandon: every barrier gives up at once, so the
-// contention fallback (SLOW path) runs on an idle GPU -- that is how the tests reach it deterministically.
-inline int fused_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("QD_SINGLE_FUSED");
-        mode = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1));
-    }
-    return mode;
-}
-int g_fused_override = -1;                                     // qd_set_single_fused_mode(); -1: follow the environment
+// qd_set_single_fused_mode(): 0 = always the three-launch path, 1 = default, 2 / 3 / 4 = every block / every block with
+// blockIdx % 7 == 3 / exactly one block skips the barrier and takes the give-up path, so that the tests reach the
+// contention fallback deterministically on an idle GPU.  A plain int: set it before launching, not concurrently.
+int g_fused_mode = 1;
 template <int MODE, int V, int W>
 int fused_capacity() {                                         // blocks of k_single_fused<MODE, V> resident at once, 0 if unusable
     static int cap = -1;
@@ -2359,18 +2383,24 @@ int fused_capacity() {                                         // blocks of k_si
             per_cu = 0;
         (void)hipGetLastError();
         int c = per_cu * num_cus();
-        cap = c > kPartialBlocks ? kPartialBlocks : c;
+        cap = c > kFusedMaxBlocks ? kFusedMaxBlocks : c;
     }
     return cap;
 }
-// one epoch sequence for ALL instantiations: a tag must never repeat on a slot set (epoch 0 = a never-written slot)
-std::atomic<unsigned> next_launch{1};
+// one epoch sequence for ALL instantiations, 64 bits: a tag never repeats on a slot set (epoch 0 = a never-written slot)
+std::atomic<uint64_t> next_launch{1};
+// Measured on MI355X (profiles/r02_k1g_fused.txt): a device-scope round trip costs 1.5-2 us, so the barrier adds ~3.5 us
+// to a kernel -- about what a kernel boundary costs -- and the load and store phases of the register-resident kernel do
+// not overlap, while the three-launch path's second read is served by the 256 MiB Infinity Cache.  One launch wins only
+// where the call is launch-bound: up to 1 Mi elements (GPU time 7.8 vs 9.7 us at 0.1 M, 10.8 vs 10.9 at 0.8 M; one host
+// launch instead of two); at 2.8 M / 5.3 M elements it measured 22 / 21 us against 16 / 17.5 us.
+constexpr int64_t kFusedMaxN = (int64_t)1 << 20;
 template <int MODE>
 int launch_single_fused(KParams& p, hipStream_t st) {
-    const int fmode = g_fused_override >= 0 ? g_fused_override : fused_mode();
+    const int fmode = g_fused_mode;
     if (fmode == 0 || ((((uintptr_t)p.x) | ((uintptr_t)p.out)) & kDataAlign) != 0) return kNotFused;
-    if ((const void*)p.x == (const void*)p.out) return kNotFused;   // in place: a give-up redo would read transformed data
-    // a captured launch would bake its barrier slot into the graph, and two replays in flight would share it
+    if ((const void*)p.x == (const void*)p.out) return kNotFused;   // in place: a block that gives up re-reads x
+    // a captured launch would bake its barrier slot and epoch into the graph, and two replays in flight would share them
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap_status) != hipSuccess || cap_status != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
@@ -2378,34 +2408,23 @@ int launch_single_fused(KParams& p, hipStream_t st) {
     }
     if (MODE == MODE_NEAREST && p.idx && p.idx_bytes == 8 && (((uintptr_t)p.idx) & 15)) return kNotFused;
     if (MODE == MODE_QDQ && p.lev8 && (((uintptr_t)p.lev8) & 3)) return kNotFused;
+    if (p.n > kFusedMaxN) return kNotFused;
     const int64_t n4 = p.n >> 2;
     const int64_t lanes = (n4 + 255) / 256;                    // blocks needed at one float4 per lane
-    // Measured on MI355X (profiles/r02_k1g_fused.txt): a device-scope round trip costs 1.5-2 us, so the barrier adds ~3.5 us
-    // to a kernel -- about what a kernel boundary costs -- and the load and store phases of the register-resident kernel do
-    // not overlap, while the three-launch path's second read is served by the 256 MiB Infinity Cache.  One launch wins only
-    // where the call is launch-bound: up to 1 Mi elements (GPU time 7.8 vs 9.7 us at 0.1 M, 10.8 vs 10.9 at 0.8 M; one host
-    // launch instead of two); at 2.8 M / 5.3 M elements it measured 22 / 21 us against 16 / 17.5 us.
-    static int64_t max_n = 0;
-    if (max_n == 0) {
-        const char* e = getenv("QD_FUSED_MAX_N");              // tuning: largest tensor (elements) taken by the one-launch kernel
-        max_n = (e && atoll(e) > 0) ? atoll(e) : ((int64_t)1 << 20);
-    }
-    if (p.n > max_n) return kNotFused;
 #define QD_FUSED(V, W)                                                                                     \
     {                                                                                                      \
         const int cap = fused_capacity<MODE, V, W>();                                                      \
         const int64_t blocks = (lanes + V - 1) / V;                                                        \
-        if (cap > 0 && blocks <= (cap < 256 ? cap : 256)) {   /* <= one block per CU: every block sweeps all G slots */ \
-            unsigned epoch = next_launch.fetch_add(1, std::memory_order_relaxed) & 0x7FFFFFFFu;            \
-            if (epoch == 0) epoch = next_launch.fetch_add(1, std::memory_order_relaxed) & 0x7FFFFFFFu;     \
+        if (cap > 0 && blocks <= cap) {                                                                    \
+            const uint64_t epoch = next_launch.fetch_add(1, std::memory_order_relaxed);                    \
             const int slot = (int)(epoch % kFusedSlots);                                                   \
             p.nvec = 0;                                                                                    \
             hipLaunchKernelGGL((k_single_fused<MODE, V, W>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, p, \
-                               slot, epoch, fmode == 2 ? 1 : 0);                                           \
+                               slot, (unsigned)epoch, (unsigned)(epoch >> 32), fmode >= 2 ? fmode - 1 : 0); \
             return check_launch();                                                                         \
         }                                                                                                  \
     }
-    QD_FUSED(1, 4) QD_FUSED(4, 4) QD_FUSED(16, 4)
+    QD_FUSED(1, 4) QD_FUSED(4, 4)
 #undef QD_FUSED
     return kNotFused;
 }
@@ -2463,8 +2482,8 @@ extern "C" {
 int qd_abi_version(void) { return 1; }
 
 int qd_set_single_fused_mode(int mode) {
-    const int prev = g_fused_override >= 0 ? g_fused_override : fused_mode();
-    g_fused_override = (mode >= 0 && mode <= 2) ? mode : -1;
+    const int prev = g_fused_mode;
+    g_fused_mode = (mode >= 0 && mode <= 4) ? mode : 1;
     return prev;
 }
 const char* qd_target_arch(void) { return "gfx950"; }
@@ -2632,16 +2651,16 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
             if (k <= 4) QD_PG(4, IDXB, BK, 4, false)                                                                \
             else if (!big) QD_PG(0, IDXB, BK, 4, false)                                                             \
             else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
-            else if (pg_turns) {                             /* k > 64: four waves take turns on 64 columns */      \
+            else {                                           /* k > 64: four waves take turns on 64 columns */      \
                 const size_t tl = (size_t)k * 64 * sizeof(float);                                                   \
                 int per_cu_t = (int)((160 * 1024) / (tl + 64));   /* LDS; the 142-163 VGPRs allow 3 blocks per CU */  \
-                if (per_cu_t > pg_bpc) per_cu_t = pg_bpc;                                                            \
+                if (per_cu_t > kTurnsBlocksPerCu) per_cu_t = kTurnsBlocksPerCu;                                      \
                 int tb = num_cus() * per_cu_t;                                                                       \
                 if (tb > blocks_all) tb = blocks_all;                                                                \
                 if (tb > (int)max_rows) tb = (int)max_rows;                                                          \
                 if (tb < 1) tb = 1;                                                                                  \
                 blocks = tb;                                                                                         \
-                if (IDXB == 8) {                                                                                     \
+                if constexpr (IDXB == 8) {                                                                           \
                     auto kern = k_point_grad_turns<IDXB, BK, 4, 4>;                                                  \
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); \
                     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, k, w.pg_part); \
@@ -2651,35 +2670,37 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
                     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, k, w.pg_part); \
                 }                                                                                                    \
             }                                                                                                       \
-            else if (big_u == 8) QD_PG(0, IDXB, BK, 8, true)                                                        \
-            else if (big_u == 16) QD_PG(0, IDXB, BK, 16, true)                                                      \
-            else QD_PG(0, IDXB, BK, 32, true)                                                                       \
         }
-        static int pg_turns = -1;                            // QD_PG_TURNS=0: one lane per column (A/B measurements)
-        if (pg_turns < 0) { const char* e = getenv("QD_PG_TURNS"); pg_turns = (e && e[0] == '0') ? 0 : 1; }
         const int blocks_all = blocks_for(n, 256 * 4 * 2);
-        static int pg_bpc = 0;                               // resident blocks per CU of the turn-token kernel (QD_PG_BPC)
-        if (pg_bpc == 0) { const char* e = getenv("QD_PG_BPC"); pg_bpc = (e && atoi(e) > 0) ? atoi(e) : 2; }   // measured: k = 128: 63.4 (2) / 65.9 (3) us
-        // A table above 64 KiB leaves ONE block per CU (4, 2 or 1 waves): the only way to keep enough bytes in flight
-        // is more loads per lane -- each wave has a quarter of a SIMD's register file or more to itself.  U float4 of g
-        // (+ their packed indices) per lane.  Measured (k = 128 / 256): U = 8: 66.6 / 121 us, 16: 68.5 / 110, 32: 79 / 119 --
-        // the waves are bound by their own VALU + LDS round trips, not by HBM latency, so this only helps a little.
-        int big_u = threads == 256 ? 8 : 16;
-        {
-            static int forced = -1;
-            if (forced < 0) { const char* e = getenv("QD_PG_U"); forced = e ? atoi(e) : 0; }
-            if (forced == 8 || forced == 16 || forced == 32) big_u = forced;
-        }
+        // resident blocks per CU of the turn-token kernel; measured at k = 128: 63.4 us (2) / 65.9 us (3).  (One lane per
+        // column under a table above 64 KiB -- one block per CU -- measured 66.6 / 110-121 us at k = 128 / 256 with 8 .. 32
+        // float4 in flight per lane: those waves are bound by their own VALU + LDS round trips.)
+        constexpr int kTurnsBlocksPerCu = 2;
         if (idx_bytes == 8) { if (nb > 1) QD_PG_K(8, true) else QD_PG_K(8, false) }
         else { if (nb > 1) QD_PG_K(1, true) else QD_PG_K(1, false) }
 #undef QD_PG_K
 #undef QD_PG
     } else {
-        int C = 256;                                     // columns of the LDS table, k*C*4 bytes <= 64 KiB
-        while ((int64_t)k * C > 16384 && C > 16) C >>= 1;
-        if (k > 16 && C > 64) C = 64;
-        hipLaunchKernelGGL(k_point_grad_generic, dim3(blocks), dim3(256), (size_t)k * C * sizeof(float), st, g, idx,
-                           idx_bytes, alpha, n, row, nb, k, C, w.pg_part);
+        // lane-private columns at any bucket size / alignment (deterministic): 256 lanes x 256 columns while the table fits
+        // 64 KiB, else one wave per block on 64 (k <= 512) or 32 columns
+        const int C = k <= 64 ? 256 : (k <= 512 ? 64 : 32);
+        const int threads = k <= 64 ? 256 : 64;
+        const size_t lds_bytes = (size_t)k * C * sizeof(float);
+        int want = blocks_for(n, threads * 4 * 4);
+        const int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
+        const int resident = num_cus() * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+        if (want > resident) want = resident;
+        if (want > max_rows) want = (int)max_rows;
+        blocks = want < 1 ? 1 : want;
+        if (idx_bytes == 8) {
+            auto kern = k_point_grad_any<8>;
+            if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, st, g, idx, alpha, n, row, nb, k, C, w.pg_part);
+        } else {
+            auto kern = k_point_grad_any<1>;
+            if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, st, g, idx, alpha, n, row, nb, k, C, w.pg_part);
+        }
     }
     hipLaunchKernelGGL(k_point_grad_final, dim3(k), dim3(256), 0, st, w.pg_part, blocks, k, grad_points);
     return check_launch();

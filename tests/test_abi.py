@@ -108,3 +108,38 @@ def test_glue_common_path_declines_what_it_does_not_handle():
         quantization.uniformQuantization(x, 16, bucket_size=4)
     with pytest.raises(ValueError):
         quantization.uniformQuantization(x, 16, bucket_size=True)
+
+
+def test_no_kernel_uses_scratch_memory(lib):
+    """Every kernel of the shipped library keeps its per-lane data in registers: `private_segment_fixed_size` (scratch
+    bytes per lane) and the VGPR spill count are 0 for all of them -- read from the code objects inside libqd_hip.so
+    (tools/kernel_meta.py).  A spilled per-lane array in an HBM-bound kernel is extra, uncounted memory traffic; round 2
+    shipped three such instantiations (272 / 528 / 228 bytes per lane in the nearest-point kernels)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_meta
+    ks = kernel_meta.kernels(_lib.LIB_PATH)
+    assert len(ks) >= 100, 'expected the whole kernel family, found %d' % len(ks)
+    bad = [(k['name'], k.get('private_segment_fixed_size', 0), k.get('vgpr_spill_count', 0)) for k in ks
+           if k.get('private_segment_fixed_size', 0) != 0 or k.get('vgpr_spill_count', 0) != 0 or k.get('uses_dynamic_stack') == 'true']
+    assert not bad, bad
+    assert all(k['vgpr_count'] <= 512 for k in ks)
+
+
+def test_no_environment_knobs_in_the_product(lib):
+    """One code path per configuration: the product library reads no environment variable (round 2 shipped nine QD_*
+    A/B knobs that switched between alternative kernel implementations at run time).  libqd_hip.so neither imports
+    getenv nor contains a QD_* name; the only run-time switch is the documented qd_set_single_fused_mode()."""
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    names = set(re.findall(rb'QD_[A-Z][A-Z0-9_]{2,}', blob))
+    assert not names, names
+    undefined = subprocess.check_output(['nm', '-D', '--undefined-only', _lib.LIB_PATH], text=True)
+    assert 'getenv' not in undefined, 'libqd_hip.so imports getenv'
+    for f in os.listdir(_lib.CSRC):
+        if f.endswith(('.hip', '.h')):
+            text = open(os.path.join(_lib.CSRC, f)).read()
+            for m in re.finditer(r'getenv\s*\(', text):
+                # allowed only inside an `#ifdef QD_TUNING` block (never defined by quantized_distillation_amd/build.py)
+                before = text[:m.start()]
+                assert before.rfind('#ifdef QD_TUNING') > before.rfind('#endif'), (f, text[m.start() - 80:m.start() + 40])
+    assert 'QD_TUNING' not in ' '.join(qb.HIPCC_FLAGS)

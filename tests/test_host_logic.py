@@ -178,3 +178,19 @@ def test_hyperspherical_helpers_match_reference():
         assert np.allclose(back.numpy(), G.z['c%d_back' % i], rtol=1e-5, atol=1e-6), i
         assert np.array_equal(hf.invert_pytorch_vector(x).numpy(), G.z['c%d_inv' % i])
         assert hf.findFirstNonZeroIndex(x) == c['first_nonzero']
+
+
+def test_bucket_invariant_division_in_exact_arithmetic():
+    """The quantize kernels divide by a bucket's alpha as q = RN(n y), r = fma(-alpha, q, n), u = fma(r, y, q) with
+    y = RN(1/alpha) (qd_common.h) instead of the reference's IEEE division (quant_functions.py:106-107).  Restated in
+    exact rational arithmetic with one explicit fp32 rounding per operation (tools/div_invariant_check.py), the result IS
+    the correctly rounded quotient on 30000 adversarial pairs inside the stated range -- and is NOT always outside it
+    (so this test can fail).  The device-side check over 10^8 pairs is tests/test_hip_parity.py::
+    test_division_by_bucket_invariant_alpha."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import div_invariant_check as dic
+    bad, outside_bad = dic.run_host(30000, seed=3, verbose=False)
+    assert bad == 0
+    assert outside_bad > 0
