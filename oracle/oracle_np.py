@@ -257,6 +257,37 @@ def ste_complicated_backward(x, g, s, bucket, tie_mode='reference'):
     return out.astype(F32).reshape(shape)
 
 
+def ste_bucket_terms(x, g, s, bucket, tie_mode='reference'):
+    """The pieces of the 'complicated' STE backward per bucket, for tolerance checks of the bucket SUM (the only
+    floating-point reduction of that function): terms t_i = g_i * (qs_i - u_i) exactly as the reference rounds them in
+    fp32 (quant_functions.py:350, :400), then
+        sb[b]        = float64 sum of the bucket's terms,
+        abs_terms[b] = float64 sum of |t_i|  (what a summation error is measured against),
+        jmax[b], jmin[b] = the two positions (relative to the bucket start) the sum is added to / subtracted from.
+    Vectorised (no Python loop over buckets)."""
+    x = np.asarray(x, dtype=F32).reshape(-1)
+    g = np.asarray(g, dtype=F32).reshape(-1)
+    n = x.size
+    q = uniform_quantize(x, s, bucket)['q'].reshape(-1)
+    sdq = scale_down(q, bucket)
+    nb, row, padded = bucket_geometry(n, bucket)
+    qs = sdq['u'].reshape(-1)[:n]
+    alpha = np.repeat(sdq['alpha'].reshape(-1), row)[:n]
+    beta = np.repeat(sdq['beta'].reshape(-1), row)[:n]
+    u = ((x - beta).astype(F32) / alpha).astype(F32)
+    term = (g * (qs - u).astype(F32)).astype(F32).astype(np.float64)
+    starts = np.arange(nb, dtype=np.int64) * row
+    sb = np.add.reduceat(term, starts)
+    abs_terms = np.add.reduceat(np.abs(term), starts)
+    if tie_mode == 'reference':
+        jmax, jmin = sdq['imax'].reshape(-1), sdq['imin'].reshape(-1)
+    else:
+        sdx = scale_down(x, bucket)
+        jmax, jmin = sdx['imax'].reshape(-1), sdx['imin'].reshape(-1)
+    return {'sb': sb, 'abs_terms': abs_terms, 'jmax': np.asarray(jmax, np.int64), 'jmin': np.asarray(jmin, np.int64),
+            'row': row, 'nb': nb}
+
+
 def truncated_ste_mask(w, grad):
     """'truncated' STE: grad[|w| > 1] = 0.  ref: cnn_models/conv_forward_model.py:263-264."""
     w = np.asarray(w, dtype=F32)

@@ -39,7 +39,6 @@ REF_ROOT = '/root/reference'
 STAGE_DIR = os.path.join(_HERE, '_ref')
 PKG_DIR = os.path.join(STAGE_DIR, 'quantization')
 FILES = ('__init__.py', 'quant_functions.py', 'help_functions.py')
-_cached = None
 
 LOOP_DIR = os.path.join(STAGE_DIR, 'loop')
 # (path relative to the reference root, [(old, new), ...] applied to the source text before compiling)
@@ -158,32 +157,89 @@ def manifest():
         return None
 
 
-def load():
-    """The reference's `quantization` package (a module object), imported from the staged bytecode
-    WITHOUT disturbing the product's package of the same name: the reference files import each
-    other absolutely (`import quantization`, `import quantization.help_functions as qhf`,
-    quant_functions.py:4-5), so for the duration of the import the name `quantization` in
-    sys.modules is pointed at the staged package, then the previous entries are put back.  The
-    reference modules keep direct references to each other in their globals, so they go on
-    working afterwards.  Returns None when nothing is staged and the reference is absent."""
-    global _cached
-    if _cached is not None:
-        return _cached
-    if not is_staged() and stage() is None:
-        return None
+_cached_by_dir = {}
+
+
+def _load_from(stage_dir):
+    """Import the `quantization` package staged under stage_dir WITHOUT disturbing the product's package of the same
+    name: the reference files import each other absolutely (`import quantization`, `import quantization.help_functions
+    as qhf`, quant_functions.py:4-5), so for the duration of the import the name `quantization` in sys.modules is pointed
+    at the staged package, then the previous entries are put back.  The reference modules keep direct references to
+    each other in their globals, so they go on working afterwards."""
+    if stage_dir in _cached_by_dir:
+        return _cached_by_dir[stage_dir]
     names = ('quantization', 'quantization.quant_functions', 'quantization.help_functions')
     saved = {k: sys.modules.pop(k) for k in names if k in sys.modules}
-    sys.path.insert(0, STAGE_DIR)
+    sys.path.insert(0, stage_dir)
     importlib.invalidate_caches()
     try:
         mod = importlib.import_module('quantization')
-        if not os.path.abspath(getattr(mod, '__file__', '') or '').startswith(STAGE_DIR):
+        if not os.path.abspath(getattr(mod, '__file__', '') or '').startswith(stage_dir):
             raise ImportError('imported %r instead of the staged reference package' % (mod,))
-        _cached = mod
+        _cached_by_dir[stage_dir] = mod
     finally:
-        sys.path.remove(STAGE_DIR)
+        sys.path.remove(stage_dir)
         for k in names:
             sys.modules.pop(k, None)
         sys.modules.update(saved)
         importlib.invalidate_caches()
-    return _cached
+    return _cached_by_dir[stage_dir]
+
+
+def load():
+    """The reference's `quantization` package (a module object), imported from the staged bytecode.  Returns None when
+    nothing is staged and the reference is absent."""
+    if not is_staged() and stage() is None:
+        return None
+    return _load_from(STAGE_DIR)
+
+
+# ---- the reference package with the two shape fixes of SURVEY.md section 8c ------------------------------------------
+# uniformQuantization_variable.backward ('complicated' STE, quant_functions.py:319-406) raises as shipped for more than
+# one bucket (:369-370: a (nb,) index tensor is added to a (nb, 1) one and expanded; :398-400: an (N, 1) product is
+# handed to a (N,) view).  The fixes are applied to the source text IN MEMORY before compiling -- the same two string
+# replacements tests/golden/gen_golden.py makes -- and only bytecode lands under oracle/_ref/patched/.
+PATCHED_DIR = os.path.join(STAGE_DIR, 'patched')
+PATCHED_PKG = os.path.join(PATCHED_DIR, 'quantization')
+_STE_A = "adder_for_buckets = torch.arange(0, self.bucket_size * total_num_buckets, self.bucket_size).long()"
+_STE_B = "(grad_output*(quantized_tensor_unscaled-(tensor-beta)/alpha).view(-1)).view(-1,1))"
+_STE_FIXES = [(_STE_A, _STE_A + ".view(-1, 1)"), (_STE_B, _STE_B + ".view(-1)")]
+
+
+def patched_is_staged():
+    return all(os.path.exists(os.path.join(PATCHED_PKG, f + 'c')) for f in FILES)
+
+
+def stage_patched(ref_root=REF_ROOT, force=False):
+    import tempfile
+    src_dir = os.path.join(ref_root, 'quantization')
+    if not all(os.path.exists(os.path.join(src_dir, f)) for f in FILES):
+        return PATCHED_PKG if patched_is_staged() else None
+    os.makedirs(PATCHED_PKG, exist_ok=True)
+    for f in FILES:
+        src = os.path.join(src_dir, f)
+        out = os.path.join(PATCHED_PKG, f + 'c')
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+            continue
+        if f != 'quant_functions.py':
+            py_compile.compile(src, cfile=out, dfile='reference/quantization/' + f, doraise=True)
+            continue
+        with open(src) as fh:
+            text = fh.read()
+        for old, new in _STE_FIXES:
+            if text.count(old) != 1:
+                raise RuntimeError('reference %s: expected exactly one occurrence of %r' % (f, old))
+            text = text.replace(old, new)
+        with tempfile.TemporaryDirectory() as tmp:              # the patched text never lands in the repository
+            tmp_src = os.path.join(tmp, f)
+            with open(tmp_src, 'w') as fh:
+                fh.write(text)
+            py_compile.compile(tmp_src, cfile=out, dfile='reference/quantization/' + f + ' (+ the two 8c shape fixes)', doraise=True)
+    return PATCHED_PKG
+
+
+def load_patched():
+    """The reference's `quantization` package whose 'complicated' backward runs for any number of buckets."""
+    if not patched_is_staged() and stage_patched() is None:
+        return None
+    return _load_from(PATCHED_DIR)

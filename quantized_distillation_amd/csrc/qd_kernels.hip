@@ -1883,9 +1883,32 @@ __global__ __launch_bounds__(256) void k_point_grad_final(const float* part, int
     if (threadIdx.x == 0) out[j] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
-// ---- K7 (vector path): the whole bucket lives in registers (x, g, q as float4), one pass ------
-// LPB lanes per bucket, V float4 per lane, as in k_bucket_vec.  Index ties: the FIRST element (in
-// memory order) at the top / bottom level of the quantized bucket (or the true arg of x).
+// ---- K7: 'complicated' STE backward (quant_functions.py:319-406) --------------------------------
+// Per bucket S = sum_i g_i (qs_i - u_i), out = g, out[jmax] += S, out[jmin] -= S.  Every TERM follows the reference's own
+// fp32 operations -- qs = (q - beta_q) / alpha_q (:350, scale_down of the quantized tensor), u = (x - beta_q) / alpha_q,
+// d = qs - u, t = g d (:400), each rounded -- so that only the order of the fp32 summation differs from the reference
+// (torch.mm over a sparse +-1 matrix): the bucket sum agrees with a float64 sum of the same terms to ~1e-7 of sum|t|.
+// (Round 2 hoisted the division out of the sum, S = (sum g (q - x)) / alpha_q: closer to exact arithmetic than the
+// reference, but 3e-7 / 6e-6 of sum|t| away from THE REFERENCE at 16 / 256 levels, because the reference's two quotients
+// are rounded before they are subtracted.)  The two quotients per element use the bucket-invariant division (three VALU
+// operations each, qd_common.h); here the quotient itself is consumed, so the form is only taken when it is exact for
+// every numerator of the bucket: alpha_q in [2^-60, 2^100] and no numerator in (0, 2^-100) -- a wave-uniform choice,
+// otherwise the IEEE division.  The level of each element (the only thing q depends on) comes from the same shortcuts as
+// K1: bucket-invariant division of (x - beta) / alpha, and level / (s-1) from the per-row table for <= 16 levels.
+template <bool FAST>
+__device__ __forceinline__ float ste_term(float g, float q, float x, float aq, float bq, float yq) {
+    float qs = q - bq;  qs = div_alpha<FAST>(qs, aq, yq);
+    float u = x - bq;   u = div_alpha<FAST>(u, aq, yq);
+    const float d = qs - u;
+    return g * d;
+}
+__device__ __forceinline__ bool ste_tiny_numerator(float x, float bq) {     // 0 < |x - beta_q| < 2^-100: outside the proven range
+    const float n = fabsf(x - bq);
+    return n < 0x1p-100f && n != 0.0f;
+}
+
+// vector path: LPB lanes per bucket, V float4 per lane, the whole bucket (x, g, q) in registers, one pass.  Index ties:
+// the FIRST element (in memory order) at the top / bottom level of the quantized bucket (or the true arg of x).
 template <int LPB, int V>
 __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const float* g, float* out, int64_t nvec,
                                                           float sm1, int tie_mode) {
@@ -1896,6 +1919,8 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t ntiles = (nvec + BPW - 1) / BPW;
+    const bool use_tab = sm1 <= 15.0f;                       // DPP rows are active or inactive as a whole here (qdq_tab)
+    const float tab = (float)(lane & 15) / sm1;
     for (int64_t t = wave; t < ntiles; t += nwaves) {
         const int64_t bkt = t * BPW + sub;
         if (bkt >= nvec) continue;
@@ -1913,32 +1938,45 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
             mx = fmaxf(mx, fmaxf(fmaxf(xv[j].x, xv[j].y), fmaxf(xv[j].z, xv[j].w)));
         }
         mn = group_min<LPB>(mn); mx = group_max<LPB>(mx);
-        float a, b, lev;
+        float a, b;
         alpha_beta(mn, mx, a, b);
+        auto quantize = [&](auto fast_c, auto tab_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            constexpr bool TAB = decltype(tab_c)::value;
+            const float y = FAST ? 1.0f / a : 0.0f;
+            float lev;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                if (TAB) {
+                    qv[j].x = qdq_tab<FAST>(xv[j].x, a, b, sm1, 0.0f, lev, tab, y); qv[j].y = qdq_tab<FAST>(xv[j].y, a, b, sm1, 0.0f, lev, tab, y);
+                    qv[j].z = qdq_tab<FAST>(xv[j].z, a, b, sm1, 0.0f, lev, tab, y); qv[j].w = qdq_tab<FAST>(xv[j].w, a, b, sm1, 0.0f, lev, tab, y);
+                } else {
+                    qv[j].x = qdq<FAST>(xv[j].x, a, b, sm1, 0.0f, lev, y); qv[j].y = qdq<FAST>(xv[j].y, a, b, sm1, 0.0f, lev, y);
+                    qv[j].z = qdq<FAST>(xv[j].z, a, b, sm1, 0.0f, lev, y); qv[j].w = qdq<FAST>(xv[j].w, a, b, sm1, 0.0f, lev, y);
+                }
+            }
+        };
+        const bool fa = !__any(!fastdiv_ok(a));              // wave-uniform
+        if (fa) { if (use_tab) quantize(std::true_type{}, std::true_type{}); else quantize(std::true_type{}, std::false_type{}); }
+        else { if (use_tab) quantize(std::false_type{}, std::true_type{}); else quantize(std::false_type{}, std::false_type{}); }
         float qmn = INFINITY, qmx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            qv[j].x = qdq(xv[j].x, a, b, sm1, 0.0f, lev); qv[j].y = qdq(xv[j].y, a, b, sm1, 0.0f, lev);
-            qv[j].z = qdq(xv[j].z, a, b, sm1, 0.0f, lev); qv[j].w = qdq(xv[j].w, a, b, sm1, 0.0f, lev);
             qmn = fminf(qmn, fminf(fminf(qv[j].x, qv[j].y), fminf(qv[j].z, qv[j].w)));
             qmx = fmaxf(qmx, fmaxf(fmaxf(qv[j].x, qv[j].y), fmaxf(qv[j].z, qv[j].w)));
         }
         qmn = group_min<LPB>(qmn); qmx = group_max<LPB>(qmx);
         float aq, bq;
         alpha_beta(qmn, qmx, aq, bq);                       // scale_down of the QUANTIZED bucket, :350
-        float sum = 0.0f;
         int jmax = 0x7fffffff, jmin = 0x7fffffff;           // index inside the bucket
         const bool ref_tie = tie_mode == QD_STE_TIE_REFERENCE;
+        bool tiny = false;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int base = (j * LPB + l) * 4;
 #define QD_STE_ELEM(c, off)                                                          \
             {                                                                        \
-                /* qs - u = ((q-bq) - (x-bq))/aq = (q-x)/aq: the division by the bucket's aq is */ \
-                /* applied once to the bucket sum below instead of twice per element (the kernel */ \
-                /* was VALU-bound: 4 IEEE divisions per element); S is compared with a tolerance, */ \
-                /* the touched positions stay integer-exact */                        \
-                sum += gv[j].c * (qv[j].c - xv[j].c);                                \
+                tiny |= ste_tiny_numerator(xv[j].c, bq);                             \
                 const bool top = ref_tie ? (qv[j].c == qmx) : (xv[j].c == mx);       \
                 const bool bot = ref_tie ? (qv[j].c == qmn) : (xv[j].c == mn);       \
                 jmax = (top && base + off < jmax) ? base + off : jmax;               \
@@ -1947,7 +1985,20 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
             QD_STE_ELEM(x, 0) QD_STE_ELEM(y, 1) QD_STE_ELEM(z, 2) QD_STE_ELEM(w, 3)
 #undef QD_STE_ELEM
         }
-        sum = group_sum<LPB>(sum) / aq; jmax = group_imin<LPB>(jmax); jmin = group_imin<LPB>(jmin);
+        float sum = 0.0f;
+        auto bucket_sum = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            const float yq = FAST ? 1.0f / aq : 0.0f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {                    // per lane in memory order, then the DPP tree
+                sum += ste_term<FAST>(gv[j].x, qv[j].x, xv[j].x, aq, bq, yq);
+                sum += ste_term<FAST>(gv[j].y, qv[j].y, xv[j].y, aq, bq, yq);
+                sum += ste_term<FAST>(gv[j].z, qv[j].z, xv[j].z, aq, bq, yq);
+                sum += ste_term<FAST>(gv[j].w, qv[j].w, xv[j].w, aq, bq, yq);
+            }
+        };
+        if (!__any(!fastdiv_ok(aq) || tiny)) bucket_sum(std::true_type{}); else bucket_sum(std::false_type{});
+        sum = group_sum<LPB>(sum); jmax = group_imin<LPB>(jmax); jmin = group_imin<LPB>(jmin);
         const bool touch = jmax != jmin;                    // constant bucket: +S and -S cancel
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -1964,7 +2015,7 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
     }
 }
 
-// ---- K7: 'complicated' STE backward, one wave per bucket --------------------------------------
+// any bucket size / alignment: one wave per bucket, four passes over the (L1/L2-resident) bucket
 __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const float* g, float* out, int64_t n,
                                                       int64_t row, int64_t first, int64_t nb, float sm1, int tie_mode) {
     const int lane = threadIdx.x & 63;
@@ -1981,6 +2032,7 @@ __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const floa
         alpha_beta(mn, mx, a, b);
         // pass 2: min/max of the QUANTIZED bucket (the reference re-runs scale_down on q, :350)
         float qmn = INFINITY, qmx = -INFINITY;
+        bool tiny = false;
         for (int64_t i = lo + lane; i < hi; i += 64) {
             float lev;
             const float q = qdq(x[i], a, b, sm1, 0.0f, lev);
@@ -1989,20 +2041,27 @@ __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const floa
         qmn = wave_min(qmn); qmx = wave_max(qmx);
         float aq, bq;
         alpha_beta(qmn, qmx, aq, bq);
-        // pass 3: S_b and the first index at the top / bottom level (or the true arg of x)
+        for (int64_t i = lo + lane; i < hi; i += 64) tiny |= ste_tiny_numerator(x[i], bq);
+        // pass 3: S_b (the reference's own per-element operations, :400) and the first index at the top / bottom level
+        // (or the true arg of x)
         float s = 0.0f;
         long long jmax = INT64_MAX, jmin = INT64_MAX;
-        for (int64_t i = lo + lane; i < hi; i += 64) {
-            float lev;
-            const float xv = x[i];
-            const float q = qdq(xv, a, b, sm1, 0.0f, lev);
-            s += g[i] * (q - xv);                        // (qs - u) * aq; divided by aq once per bucket below, cf. :400
-            const bool top = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmx) : (xv == mx);
-            const bool bot = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmn) : (xv == mn);
-            if (top && (long long)i < jmax) jmax = i;
-            if (bot && (long long)i < jmin) jmin = i;
-        }
-        s = wave_sum(s) / aq;
+        auto pass3 = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            const float yq = FAST ? 1.0f / aq : 0.0f;
+            for (int64_t i = lo + lane; i < hi; i += 64) {
+                float lev;
+                const float xv = x[i];
+                const float q = qdq(xv, a, b, sm1, 0.0f, lev);
+                s += ste_term<FAST>(g[i], q, xv, aq, bq, yq);
+                const bool top = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmx) : (xv == mx);
+                const bool bot = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmn) : (xv == mn);
+                if (top && (long long)i < jmax) jmax = i;
+                if (bot && (long long)i < jmin) jmin = i;
+            }
+        };
+        if (!__any(!fastdiv_ok(aq) || tiny)) pass3(std::true_type{}); else pass3(std::false_type{});
+        s = wave_sum(s);
         jmax = wave_min_ll(jmax);
         jmin = wave_min_ll(jmin);
         // pass 4: out = g, +S at jmax, -S at jmin (they cancel when the bucket is constant)

@@ -9,6 +9,8 @@ from hypothesis import strategies as st
 import quantization
 from oracle import oracle_c as oc
 
+import errlog
+
 import os
 
 pytestmark = pytest.mark.gpu
@@ -88,7 +90,7 @@ def test_nonuniform_matches_oracle(n, bucket, k, seed, kind, dup):
     g = rng.randn(n).astype(np.float32)
     _, gp = fn.backward(torch.from_numpy(g).to(DEV))
     want, absum = oc.point_grad(g, rm['idx'], rm['alpha'], bucket, k)
-    assert np.all(np.abs(gp.cpu().numpy().astype(np.float64) - want) <= 4e-6 * absum + 1e-30)
+    errlog.check_sum('K6 point gradient, property soak (any n / bucket / k)', gp.cpu().numpy(), want, absum, (n, bucket, k, seed), n_terms=n)
 
 
 @settings(max_examples=30 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
@@ -117,8 +119,7 @@ def test_ste_backward_matches_oracle(n, bucket, s, seed, kind):
     fn.forward(torch.from_numpy(x).to(DEV))
     out = fn.backward(torch.from_numpy(g).to(DEV)).cpu().numpy()
     ref = oc.ste_complicated_backward(x, g, s, bucket)
-    atol = 4e-6 * (np.abs(g).mean() + 1e-30) * min(bucket, n) + 1e-30
-    assert np.allclose(out, ref, rtol=0, atol=atol)
+    errlog.check_ste('K7 bucket sum, property soak', out, x, g, s, bucket, (n, bucket, s, seed, kind))
     # tie rule: only the first arg-min / arg-max of each bucket of the QUANTIZED tensor may be touched.  (A
     # correction below half an ulp of g leaves g unchanged, and whether it does depends on the summation
     # order, so "touched" is compared as a subset plus the positions whose correction is clearly visible.)
@@ -181,7 +182,8 @@ def test_uniform_subtract_mean_matches_oracle(n, bucket, s, seed, kind, clamp):
     q, sf = quantization.uniformQuantization(xd, s, bucket_size=bucket, subtract_mean=True, max_element=clamp)
     mean = float(sf.mean_tensor)
     ref_mean = float(np.float32(x.astype(np.float64).mean()))
-    assert abs(mean - ref_mean) <= 2e-7 * max(1.0, abs(ref_mean))
+    errlog.check_mean('qd_mean_f32, property soak', mean, x.astype(np.float64).mean(), float(np.abs(x.astype(np.float64)).mean()),
+                      (n, seed, kind), n_terms=n)
     r = oc.uniform_quantize(x, s, bucket, max_element=clamp, subtract_mean=True, mean=mean, want_idx=False, want_lev=False)
     assert np.array_equal(q.cpu().numpy(), r['q'])
     assert np.array_equal(sf.alpha.cpu().numpy().reshape(-1), r['alpha'])

@@ -6,6 +6,8 @@ import pytest
 
 from oracle import oracle_np as onp
 
+import errlog
+
 
 def _b(c):
     return c['bucket']
@@ -58,7 +60,7 @@ def test_point_grad_all_cases(golden_nonuniform):
         for idx_key, gp_key in (('idx_pre', 'gp'), ('idx', 'gp_np'), ('idx_pre2', 'gp2')):
             got, absum = onp.point_grad(g, G.arr('n', i, idx_key), G.arr('n', i, 'alpha'), _b(c), c['k'])
             ref = G.arr('n', i, gp_key).astype(np.float64)
-            assert np.all(np.abs(got - ref) <= 2e-6 * absum + 1e-30), (i, c, got, ref)
+            errlog.check_sum("oracle (numpy, float64) vs the reference's fp32 gradPointTensor (golden)", got, ref, absum, (i, c, idx_key))
 
 
 def test_ste_complicated_all_cases(golden_ste):
@@ -67,8 +69,8 @@ def test_ste_complicated_all_cases(golden_ste):
         x, g = G.arr('s', i, 'x'), G.arr('s', i, 'g')
         out = onp.ste_complicated_backward(x, g, c['s'], _b(c), tie_mode='reference')
         ref = G.arr('s', i, 'gout')
-        scale = np.abs(g).sum() / g.size * c['bucket']           # magnitude of a bucket sum
-        assert np.allclose(out, ref, rtol=0, atol=3e-6 * scale), (i, c, np.abs(out - ref).max())
+        errlog.check_ste("oracle (numpy) vs the (patched) reference's fp32 STE output (golden)", out, x, g, c['s'], _b(c), (i, c),
+                         ref_out=ref)
         # elements that are neither argmax nor argmin of their bucket pass through untouched
         untouched = out == g
         assert untouched.sum() >= g.size - 2 * (-(-g.size // c['bucket']))
