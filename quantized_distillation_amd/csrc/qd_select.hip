@@ -15,6 +15,7 @@
 // LDS (<= 32 targets = 128 KiB of the 160 KiB), one 1024-lane block per CU.  Exact for every float (NaNs order last,
 // -0 before +0); equal keys are the same value, so ties need no care.
 #include "qd_common.h"
+#include <atomic>
 
 #include "../../include/qd_hip.h"
 
@@ -332,13 +333,19 @@ int qd_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int m, f
     const int cap = cus < MAX_BLOCKS ? cus : MAX_BLOCKS;
     const int blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     const size_t lds = (size_t)m * SUB_BINS * sizeof(uint32_t);
-    static bool lds_raised = false;
-    if (!lds_raised) {
-        (void)hipFuncSetAttribute((const void*)k_sel_hist_sub<TOP_BITS, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  MAX_RANKS * SUB_BINS * 4);
-        (void)hipFuncSetAttribute((const void*)k_sel_hist_sub<TOP_BITS + SUB_BITS, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  MAX_RANKS * SUB_BINS * 4);
-        lds_raised = true;
+    // the attribute is per DEVICE: raise it once for each device this process launches on
+    static std::atomic<unsigned long long> lds_raised{0};
+    const unsigned long long dev_bit = 1ull << (dev & 63);
+    if (!(lds_raised.load(std::memory_order_relaxed) & dev_bit)) {
+        const hipError_t e1 = hipFuncSetAttribute((const void*)k_sel_hist_sub<TOP_BITS, U>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAX_RANKS * SUB_BINS * 4);
+        const hipError_t e2 = hipFuncSetAttribute((const void*)k_sel_hist_sub<TOP_BITS + SUB_BITS, U>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAX_RANKS * SUB_BINS * 4);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            (void)hipGetLastError();
+            return (int)(e1 != hipSuccess ? e1 : e2);          // positive hipError_t, as every entry point reports launch failures
+        }
+        lds_raised.fetch_or(dev_bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((k_sel_hist_top<U>), dim3(blocks), dim3(SEL_THREADS), 0, st, x, n, part);
     hipLaunchKernelGGL(k_sel_sum_top, dim3(TOP_BINS / 64), dim3(256), 0, st, part, blocks, hist);

@@ -142,8 +142,12 @@ PyObject* glue_uniform(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
         check_rc(qd_uniform_f32(x.data_ptr<float>(), q.data_ptr<float>(), n, bucket, static_cast<int>(levels), abp, abp + nb,
                                 nullptr, mean_ptr, clamp, static_cast<float>(max_element), stochastic, seed,
                                 nb == 1 ? ws : nullptr, nb == 1 ? ws_bytes : 0, stream));
-    } else if (subtract_mean) {
-        mean = empty_f32({1}, dev);
+    } else {                                               // nothing to scale: defined values, not uninitialised memory
+        ab.zero_();
+        if (subtract_mean) {
+            mean = empty_f32({1}, dev);
+            mean.zero_();
+        }
     }
     PyObject* out = PyTuple_New(5);
     PyTuple_SET_ITEM(out, 0, THPVariable_Wrap(q));

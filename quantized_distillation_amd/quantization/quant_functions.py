@@ -46,6 +46,12 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _version_of(t):
+    """Version counter of the tensor the lazy arg indices will be read from, or None for an inference tensor (those do
+    not track versions -- `._version` raises -- and cannot be modified in place outside inference mode: no guard needed)."""
+    return None if t.is_inference() else t._version
+
+
 class ScalingFunction(object):
     """Scaling of a tensor to [0,1] and its inverse (ref: quant_functions.py:7-152).
 
@@ -109,9 +115,12 @@ class ScalingFunction(object):
             if self._ab_slab is None:
                 return
             nb = _geometry(self._n, self.bucket_size)[0]
-            ab = self._ab_slab[self._ab_off:self._ab_off + 2 * nb]
+            # a private copy of the 2 * nb floats, and the 1 MiB slab is let go: an object that is kept around (lists of
+            # scaling functions, the Huffman accounting of help_functions) must not pin a slab shared with 65536 other calls
+            ab = self._ab_slab[self._ab_off:self._ab_off + 2 * nb].clone()
             ab = ab.view(2, 1) if self.bucket_size is None else ab.view(2, nb, 1)
             self._ab = ab
+            self._ab_slab = None
         self._alpha, self._beta = ab.unbind(0)
 
     @property
@@ -212,7 +221,7 @@ class ScalingFunction(object):
         self._idx_min_rows = None
         self._idx_max_rows = None
         self._arg_source = tensor
-        self._arg_version = tensor._version
+        self._arg_version = _version_of(tensor)
         if overwritten:                # the data is about to be replaced: materialise now
             self._compute_arg_indices()
 
@@ -220,7 +229,7 @@ class ScalingFunction(object):
         t = self._arg_source
         if t is None:
             return
-        if t._version != self._arg_version:
+        if self._arg_version is not None and t._version != self._arg_version:
             # the reference computes the indices eagerly inside scale_down (ref: :85-90); here they are
             # taken from the tensor on first access, which is only the same thing while it is unchanged
             raise RuntimeError('idx_min_rows / idx_max_rows were requested after the tensor passed to scale_down / the '
@@ -379,7 +388,7 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
         d['_n'] = n
         d['_ab'] = ab
         d['_arg_source'] = x_read
-        d['_arg_version'] = tensor._version
+        d['_arg_version'] = _version_of(x_read)          # of the tensor actually retained (a non-contiguous input was copied)
         if mean is not None:
             d['_mean_buf'] = mean
             d['mean_tensor'] = mean.view(())                                         # 0-dim, ref: :67
@@ -417,7 +426,7 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
         sf.mean_tensor = 0                                                           # ref: :70
     if not modify_in_place:
         sf._arg_source = x_read
-        sf._arg_version = tensor._version
+        sf._arg_version = _version_of(x_read)            # of the tensor actually retained (a non-contiguous input was copied)
     return q, sf
 
 

@@ -156,3 +156,67 @@ def test_lazy_arg_indices_guard_still_holds():
     x.add_(1.0)
     with pytest.raises(RuntimeError):
         sf.idx_min_rows
+
+
+def test_lazy_arg_indices_on_a_noncontiguous_view_of_a_modified_base():
+    """Round-2 advisor finding: the guard compared the version counter of the ORIGINAL tensor with the one recorded for
+    the contiguous copy actually retained, so `w.t()` of a parameter that had ever been written in place raised a
+    spurious 'modified in place' error.  The guard now follows the retained tensor."""
+    y = torch.randn(64, 48, device=DEV)
+    y.add_(1.0)                                              # version counter > 0
+    q, sf = quantization.uniformQuantization(y.t(), 16, bucket_size=256)
+    want = oc.uniform_quantize(host(y.t().contiguous()), 16, 256)
+    assert np.array_equal(host(q), want['q'])
+    sf2 = ScalingFunction('linear', False, False, 256)
+    sf2.scale_down(y.t().contiguous())
+    assert torch.equal(sf.idx_min_rows, sf2.idx_min_rows) and torch.equal(sf.idx_max_rows, sf2.idx_max_rows)
+    # and through the general path's other entry (max_element set -> not the common path)
+    q3, sf3 = quantization.uniformQuantization(y.t(), 16, bucket_size=256, max_element=10.0)
+    assert torch.equal(sf3.idx_min_rows, sf2.idx_min_rows)
+
+
+def test_inference_mode_tensors_quantize():
+    """Round-2 advisor finding: inference tensors do not track a version counter (`._version` raises), and the common
+    path declines them, so uniformQuantization / scale_down / nonUniformQuantization failed outright under
+    torch.inference_mode()."""
+    with torch.inference_mode():
+        x = torch.randn(5000, device=DEV)
+        q, sf = quantization.uniformQuantization(x, 16, bucket_size=256)
+        want = oc.uniform_quantize(host(x), 16, 256)
+        assert np.array_equal(host(q), want['q'])
+        assert np.array_equal(host(sf.alpha).reshape(-1), want['alpha'].reshape(-1))
+        sf2 = ScalingFunction('linear', False, False, 256)
+        u = sf2.scale_down(x)
+        assert np.array_equal(host(u).reshape(-1)[:5000], oc.scale_down(host(x), 256)['u'])
+        assert sf2.idx_min_rows.shape == (20, 1) and torch.equal(sf.idx_min_rows, sf2.idx_min_rows)
+        pts = torch.tensor([0.0, 0.3, 0.7, 1.0], device=DEV)
+        qn, idx, _ = quantization.nonUniformQuantization(x, pts, bucket_size=256)
+        r = oc.nonuniform_quantize(host(x), host(pts), 256)
+        assert np.array_equal(host(qn), r['q']) and np.array_equal(host(idx), r['idx'])
+
+
+def test_retained_scaling_functions_do_not_pin_slabs():
+    """alpha / beta of the common path live in a 1 MiB slab shared by many calls; an object that is KEPT (the Huffman
+    accounting keeps one ScalingFunction per tensor, ref: help_functions.py:200-233) copies its 2 * nb floats out when they
+    are first read and lets the slab go.  64 kept objects, each carved from a different slab: device memory held by them
+    drops from 64 MiB to a few KiB once their alpha has been read."""
+    torch.cuda.synchronize()
+    small = torch.randn(300, device=DEV)
+    filler = torch.randn(256 * 30000, device=DEV)            # 30000 buckets = 60000 floats: a fresh slab every 4 calls
+    kept = []
+    for i in range(64):
+        kept.append(quantization.uniformQuantization(small, 16, bucket_size=256)[1])
+        for _ in range(5):
+            quantization.uniformQuantization(filler, 16, bucket_size=256)
+    assert all(took_common_path(sf) for sf in kept)
+    slabs = {sf._ab_slab.data_ptr() for sf in kept}
+    assert len(slabs) >= 32, 'the test did not spread the kept objects over many slabs'
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    for sf in kept:
+        assert sf.alpha.shape == (1, 1) and sf._ab_slab is None
+    torch.cuda.synchronize()
+    after = torch.cuda.memory_allocated()
+    assert before - after >= (len(slabs) - 2) * (1 << 20), (before, after, len(slabs))
+    want = oc.uniform_quantize(host(small), 16, 256)
+    assert all(np.array_equal(host(sf.alpha).reshape(-1), want['alpha'].reshape(-1)) for sf in kept)

@@ -99,3 +99,43 @@ def test_nonuniform_2bit_on_wrn_shape_list():
             qd, idxd, _ = quantization.nonUniformQuantization(dev[i], points[i], bucket_size=bucket)
             wd = oracle_c.nonuniform_quantize(t.numpy(), pts_host[i], bucket, mode='distance')
             assert np.array_equal(qd.cpu().numpy(), wd['q']) and np.array_equal(idxd.cpu().numpy(), wd['idx']), (i, 'distance rule')
+
+
+def test_point_gradient_vs_the_staged_reference_on_wrn_shapes():
+    """K6 against the REFERENCE's own fp32 `gradPointTensor` (quant_functions.py:493-503: k masked_select + sum passes on
+    the host) at WideResNet-16-22 tensor shapes, incl. the largest one (1408 x 1408 x 3 x 3 = 17.8 M elements): the distance
+    is the sum of both sides' fp32 summation errors and must stay inside north_star's 1e-6 of sum |g alpha|; the distance
+    of each side from the float64 oracle is recorded next to it (profiles/r03_reduction_error.txt)."""
+    from oracle import ref_stage
+    refq = ref_stage.load()
+    if refq is None:
+        pytest.skip('reference quantizer not staged under oracle/_ref')
+    import quantization.help_functions as qhf
+    host = _weights('wrn_16_22')
+    k, bucket = 4, 256
+    picks = [i for i, t in enumerate(host) if t.numel() in (1408 * 1408 * 9, 704 * 1408 * 9, 352 * 352 * 9, 16 * 3 * 9, 1408, 10 * 1408)]
+    seen = set()
+    for i in picks:
+        t = host[i]
+        if t.numel() in seen:
+            continue
+        seen.add(t.numel())
+        td = t.to(DEV)
+        scaling = quantization.ScalingFunction('linear', False, False, bucket, False)
+        pts = qhf.initialize_quantization_points(td, scaling, k)
+        g = torch.randn(t.shape, generator=torch.Generator().manual_seed(100 + i)) * 1e-3
+        fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=td)
+        q = fn.forward(None, pts)
+        _, gp = fn.backward(g.to(DEV))
+        rf = refq.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=t.clone())
+        qr = rf.forward(None, pts.cpu())
+        assert np.array_equal(q.cpu().numpy(), qr.numpy()), (i, 'forward differs from the reference')
+        _, gpr = rf.backward(g.clone())
+        want = oracle_c.nonuniform_quantize(t.numpy(), pts.cpu().numpy(), bucket, mode='midpoint')
+        wg, absum = oracle_c.point_grad(g.numpy(), want['idx'], want['alpha'], bucket, k)
+        tag = (i, tuple(t.shape))
+        errlog.check_sum("K6 vs the staged reference's own fp32 gradPointTensor, WRN-16-22 shapes", gp.cpu().numpy(), gpr.numpy(), absum,
+                         tag, n_terms=t.numel())
+        errlog.check_sum('K6 vs float64 oracle, WRN-16-22 shapes', gp.cpu().numpy(), wg, absum, tag, n_terms=t.numel())
+        errlog.check_sum("the staged reference's fp32 gradPointTensor vs float64 oracle, WRN-16-22 shapes", gpr.numpy(), wg, absum, tag,
+                         n_terms=t.numel(), tol=1e-5)

@@ -458,6 +458,48 @@ def test_nonuniform_random_vs_c_oracle(k):
             assert np.bincount(host(idx).reshape(-1), minlength=k).sum() == n
 
 
+@pytest.mark.parametrize('bucket,k', [(100, 4), (100, 600), (1000, 4), (1000, 600), (100, 64), (100, 100), (33, 16), (256, 600),
+                                      (None, 700), (256, 1024), (1000, 1024)])
+def test_point_gradient_deterministic_and_within_1e6_on_every_path(bucket, k):
+    """qd_point_grad_f32 promises a deterministic two-stage reduction on EVERY path (include/qd_hip.h).  Round 2's path for
+    non-power-of-two buckets, k > 512 and misaligned index pointers used float LDS atomics, whose order is not fixed; it
+    now runs on lane-private columns like the fast path.  20 launches each -- uint8 and int64 indices, aligned and
+    misaligned index pointers -- must give bit-identical grad_points, within 1e-6 of sum |g alpha| of the float64 oracle
+    (ref: quant_functions.py:493-503)."""
+    lib = _lib.load()
+    rng = np.random.RandomState(k * 7 + (bucket or 1))
+    n = 700001
+    g = rng.randn(n).astype(np.float32)
+    idx = rng.randint(0, k, size=n).astype(np.int64)
+    nb = 1 if bucket is None else (n + bucket - 1) // bucket
+    alpha = (np.abs(rng.randn(nb)) + 0.1).astype(np.float32)
+    want, absum = oc.point_grad(g, idx, alpha, bucket, k)
+    gd, ad = dev(g), dev(alpha)
+    ws = torch.empty(lib.qd_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    variants = [('int64', dev(idx), 8, 0)]
+    pad = torch.zeros(n + 1, dtype=torch.int64, device=DEV)
+    pad[1:] = dev(idx)
+    variants.append(('int64 at +8 bytes', pad[1:], 8, 0))                 # index pointer not 16-byte aligned
+    if k <= 256:
+        variants.append(('uint8', dev(idx.astype(np.uint8)), 1, 0))
+        p8 = torch.zeros(n + 1, dtype=torch.uint8, device=DEV)
+        p8[1:] = dev(idx.astype(np.uint8))
+        variants.append(('uint8 at +1 byte', p8[1:], 1, 0))
+    for name, it, ib, _ in variants:
+        outs = []
+        for rep in range(20):
+            out = torch.full((k,), float('nan'), device=DEV)
+            _lib.check(lib.qd_point_grad_f32(gd.data_ptr(), it.data_ptr(), ib, ad.data_ptr(), n, bucket or 0, k, out.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), st))
+            outs.append(out)
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), (bucket, k, name, 'run-to-run difference')
+        errlog.check_sum('K6 point gradient, every path (bucket %s, k = %d)' % (bucket, k), host(outs[0]), want, absum,
+                         (bucket, k, name), n_terms=n)
+
+
 def test_search_sorted_handle_query():
     from quantization.quant_functions import SearchSorted
     x = np.random.RandomState(0).rand(10000).astype(np.float32)

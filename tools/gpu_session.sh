@@ -1,0 +1,44 @@
+#!/bin/bash
+# One MI355X lease, driven by a list of step names:   gpurun -- 'bash tools/gpu_session.sh smoke tests bench'
+# Every step writes under gpurun_out/ (merged back by gpurun); tools/summarize_*.py turn the logs into profiles/r03_*.
+#   smoke      __graft_entry__.smoke()
+#   tests      the whole GPU suite (records the achieved reduction errors in gpurun_out/reduction_error.jsonl)
+#   bench      bench.py with the default flags, then with the driver's (--steps 20 --warmup 5)
+#   prof       rocprofv3 --kernel-trace --stats of the bench command + the two PMC passes (FETCH_SIZE, WRITE_SIZE)
+#   kernels    tools/bench_kernels.py (every kernel of the path, steady state)
+#   pmck       per-kernel PMC traffic of tools/pmc_probe.py
+#   div        tools/div_invariant_check.py --pairs 1e9 (the long run of the division proof)
+#   ragged     tools/ragged_probe.py
+#   api        tools/profile_api_overhead.py
+#   soak       property tests with QD_SOAK=10
+#   stack      ROCm / driver / torch versions of the box
+set +e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
+export TMPDIR=/tmp
+cd $R
+for step in "$@"; do
+  echo "== $step"
+  case $step in
+    stack)   (cat /opt/rocm/.info/version 2>/dev/null; python -c "import torch; print('torch', torch.__version__, 'hip', torch.version.hip, torch.cuda.get_device_name(0))"; rocminfo 2>/dev/null | grep -m3 -i "gfx\|Marketing"; nproc; lscpu | grep -m1 "Model name") > gpurun_out/stack.txt 2>&1; cat gpurun_out/stack.txt ;;
+    smoke)   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log ;;
+    tests)   rm -f gpurun_out/reduction_error.jsonl; timeout 3000 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.log; python tools/summarize_reduction_error.py > gpurun_out/reduction_error.txt 2>&1; cat gpurun_out/reduction_error.txt ;;
+    bench)   timeout 1500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-900 gpurun_out/bench.json
+             timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-distill 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('driver flags:', d['value'], d['roofline']['avg_launch_us'], d['roofline']['frac'])" ;;
+    prof)    rm -rf gpurun_out/prof_stats gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+             (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o bench -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-distill > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "stats rc=$?"
+             for c in FETCH_SIZE WRITE_SIZE; do
+               (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o bench -- python $R/bench.py --steps 10 --warmup 2 --precondition-s 0.05 --no-cpu-baseline --no-distill > /dev/null 2> $R/gpurun_out/pmc_$c.err); echo "pmc $c rc=$?"
+             done ;;
+    pmck)    rm -rf gpurun_out/pmcK_FETCH_SIZE gpurun_out/pmcK_WRITE_SIZE
+             for c in FETCH_SIZE WRITE_SIZE; do
+               (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcK_$c -o probe -- python $R/tools/pmc_probe.py > /dev/null 2> $R/gpurun_out/pmcK_$c.err); echo "pmcK $c rc=$?"
+             done ;;
+    kernels) timeout 1200 python tools/bench_kernels.py 2>&1 | grep -v amdgpu.ids > gpurun_out/kernels.txt; tail -5 gpurun_out/kernels.txt ;;
+    div)     timeout 900 python tools/div_invariant_check.py --pairs 1e9 --cpu 100000 > gpurun_out/div_invariant.txt 2>&1; echo "div rc=$?"; cat gpurun_out/div_invariant.txt ;;
+    ragged)  timeout 600 python tools/ragged_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/ragged.txt; cat gpurun_out/ragged.txt ;;
+    api)     timeout 600 python tools/profile_api_overhead.py 2>&1 | grep -v amdgpu.ids > gpurun_out/api_overhead.txt; head -8 gpurun_out/api_overhead.txt ;;
+    soak)    QD_SOAK=10 timeout 1500 python -m pytest tests/test_hip_property.py -x -q -m gpu > gpurun_out/property_soak.log 2>&1; tail -2 gpurun_out/property_soak.log ;;
+    *)       echo "unknown step $step" ;;
+  esac
+done

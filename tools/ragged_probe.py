@@ -17,7 +17,8 @@ for i in range(300):
     if i == 0:
         x0 = torch.randn(N, device=dev)
 torch.cuda.synchronize()
-for bucket, extra in ((256, 0), (256, 255), (1024, 1000), (4096, 0), (4096, 4000), (8192, 0), (8192, 8000), (2000, 1999), (8000, 7000)):
+for bucket, extra in ((256, 0), (256, 255), (1024, 1000), (4096, 0), (4096, 4000), (4096, 4001), (8192, 0), (8192, 8000), (8192, 8003), (2000, 1999),
+                      (2000, 1), (8000, 7000), (8000, 7002), (1000, 0), (1000, 999), (513, 0), (513, 511)):
     n = N + extra if extra else N
     xs = [torch.randn(n, device=dev) for _ in range(3)]
     live = [None] * 3
