@@ -1235,13 +1235,18 @@ __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab
 // "last block", no flag that one block sets and another must see: every block's output depends only on x and on slot
 // values it has itself observed with this launch's tag (round 2's protocol -- a relaxed gave_up counter read by the last
 // block out -- could miss a departure and leave a slice unwritten).
-// A slot is two 8-byte words {min bits | epoch low half << 32}, {max bits | epoch high half << 32}; each word is written
-// and read with one atomic access, so a value can never be seen with another launch's tag.  The epoch is a 64-bit host
-// counter that never repeats (a 31-bit one wrapped after 2^31 launches, and slots that only large grids touch could
-// still carry the old tag).  Should two launches ever share a slot set while both are running (more than kFusedSlots
-// of these kernels in flight), they overwrite each other's tags, their sweeps fail, and both take the give-up path:
-// slow, still correct.  The slots live in a __device__ array (zero-initialised when the module is loaded, per device
-// and per process; epoch 0 is never used), not in the caller's workspace, whose contents are undefined by contract.
+// A slot is two 8-byte words {min bits | tag_min << 32}, {max bits | tag_max << 32}; each word is written and read with
+// one atomic access, so a value can never be seen with another launch's tag.  BOTH tags are unique to the launch among
+// all launches that can have touched the slot: the host draws a 64-bit epoch that never repeats and sets
+// tag_min = its low half, tag_max = low half ^ (high half * odd constant), both non-zero (a never-written slot is 0 | 0).
+// A slot left over from another launch matches tag_min only if its epoch has the same low half, i.e. lies 2^32 launches
+// back, and then its tag_max differs because the high half does.  (Tagging the two words with the two HALVES of the epoch
+// does not work: the high half is the same for 2^32 launches in a row, so a sweep could pair this launch's min with the max
+// a previous launch left in the slot.  A 31-bit epoch alone wrapped after 2^31 launches, and slots that only large grids
+// touch could still carry the old tag.)  Should two launches ever share a slot set while both are running (more than
+// kFusedSlots of these kernels in flight), they overwrite each other's tags, their sweeps fail, and both take the give-up
+// path: slow, still correct.  The slots live in a __device__ array (zero-initialised when the module is loaded, per device
+// and per process), not in the caller's workspace, whose contents are undefined by contract.
 constexpr int kFusedSlots = 64;
 constexpr int kFusedMaxBlocks = 256;                   // <= one block per CU: every block sweeps all G slots
 constexpr long long kBarrierTimeout = 200000;          // 2 ms of the 100 MHz wall clock
@@ -1275,14 +1280,14 @@ __device__ __forceinline__ f4 transform4(const KParams& p, const PointTable* T, 
 
 // One sweep over the G slots (all threads of the block): true when every slot carries this launch's epoch; then
 // (mn, mx) is the fold of all partials (NaN in any of them poisons both, as torch's min/max do).
-__device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, unsigned ep_lo, unsigned ep_hi, float* red,
+__device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, unsigned tag_min, unsigned tag_max, float* red,
                                             float& mn, float& mx) {
     float fmn = INFINITY, fmx = -INFINITY;
     int fnan = 0, missing = 0;
     for (unsigned i = threadIdx.x; i < G; i += blockDim.x) {
         const unsigned long long a = ld_agent(&ctl->slot[i][0]);
         const unsigned long long b = ld_agent(&ctl->slot[i][1]);
-        missing |= ((unsigned)(a >> 32) != ep_lo) | ((unsigned)(b >> 32) != ep_hi);
+        missing |= ((unsigned)(a >> 32) != tag_min) | ((unsigned)(b >> 32) != tag_max);
         const float pm = __uint_as_float((unsigned)a), px = __uint_as_float((unsigned)b);
         fnan |= (pm != pm);
         fmn = fminf(fmn, pm);
@@ -1298,7 +1303,7 @@ __device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, uns
 // V float4 per lane at W waves per SIMD (W = 4: 128 VGPRs).  The launcher uses it up to 1 Mi elements (V <= 4).
 template <int MODE, int V, int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
-void k_single_fused(KParams p, int slot_set, unsigned ep_lo, unsigned ep_hi, int give_up_mode) {
+void k_single_fused(KParams p, int slot_set, unsigned tag_min, unsigned tag_max, int give_up_mode) {
     __shared__ PointTable Ts;
     __shared__ float red[32];
     __shared__ int s_timed_out;
@@ -1344,8 +1349,8 @@ void k_single_fused(KParams p, int slot_set, unsigned ep_lo, unsigned ep_hi, int
 
     // ---- publish (also by a block that is about to give up: the others must not wait for it) ----
     if (threadIdx.x == 0) {
-        st_agent(&ctl->slot[blockIdx.x][0], (unsigned long long)__float_as_uint(mn) | ((unsigned long long)ep_lo << 32));
-        st_agent(&ctl->slot[blockIdx.x][1], (unsigned long long)__float_as_uint(mx) | ((unsigned long long)ep_hi << 32));
+        st_agent(&ctl->slot[blockIdx.x][0], (unsigned long long)__float_as_uint(mn) | ((unsigned long long)tag_min << 32));
+        st_agent(&ctl->slot[blockIdx.x][1], (unsigned long long)__float_as_uint(mx) | ((unsigned long long)tag_max << 32));
         s_timed_out = forced ? 1 : 0;
     }
     __syncthreads();
@@ -1355,7 +1360,7 @@ void k_single_fused(KParams p, int slot_set, unsigned ep_lo, unsigned ep_hi, int
     if (!forced) {
         const long long t0 = wall_clock64();
         for (;;) {
-            if (sweep_slots(ctl, G, ep_lo, ep_hi, red, mn, mx)) { met = true; break; }
+            if (sweep_slots(ctl, G, tag_min, tag_max, red, mn, mx)) { met = true; break; }
             if (threadIdx.x == 0 && wall_clock64() - t0 > kBarrierTimeout) s_timed_out = 1;
             __syncthreads();
             if (s_timed_out) break;
@@ -2475,11 +2480,17 @@ int launch_single_fused(KParams& p, hipStream_t st) {
         const int cap = fused_capacity<MODE, V, W>();                                                      \
         const int64_t blocks = (lanes + V - 1) / V;                                                        \
         if (cap > 0 && blocks <= cap) {                                                                    \
-            const uint64_t epoch = next_launch.fetch_add(1, std::memory_order_relaxed);                    \
+            uint64_t epoch;                                                                                \
+            unsigned tag_min, tag_max;                                                                     \
+            do {                                            /* both tags non-zero: 0 | 0 is a never-written slot */ \
+                epoch = next_launch.fetch_add(1, std::memory_order_relaxed);                               \
+                tag_min = (unsigned)epoch;                                                                 \
+                tag_max = tag_min ^ ((unsigned)(epoch >> 32) * 0x9E3779B9u);                               \
+            } while (tag_min == 0u || tag_max == 0u);                                                      \
             const int slot = (int)(epoch % kFusedSlots);                                                   \
             p.nvec = 0;                                                                                    \
             hipLaunchKernelGGL((k_single_fused<MODE, V, W>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, p, \
-                               slot, (unsigned)epoch, (unsigned)(epoch >> 32), fmode >= 2 ? fmode - 1 : 0); \
+                               slot, tag_min, tag_max, fmode >= 2 ? fmode - 1 : 0);          \
             return check_launch();                                                                         \
         }                                                                                                  \
     }

@@ -86,27 +86,28 @@ def test_slab_slices_never_alias_across_calls_and_rollovers():
             x = torch.randn(n, generator=g) * float(1 + rep)
             q, sf = quantization.uniformQuantization(x.to(DEV), 16, bucket_size=256)
             kept.append((x, q, sf))
+    # where each object's pair lives, BEFORE it is read (reading copies the 2 * nb floats out and lets the slab go)
     slabs = set()
+    by_slab = {}
+    for x, q, sf in kept:
+        nb = (x.numel() + 255) // 256
+        if sf.__dict__.get('_ab_slab') is not None:
+            slabs.add(sf._ab_slab.data_ptr())
+            by_slab.setdefault(sf._ab_slab.data_ptr(), []).append((sf._ab_off, sf._ab_off + 2 * nb))
+        else:
+            assert 2 * nb > (1 << 18) // 4                    # the big ones were allocated on their own
+    assert len(slabs) >= 3, 'the sizes above fill more than two 1 MiB slabs'
+    # ranges carved from one slab are disjoint
+    for ranges in by_slab.values():
+        ranges.sort()
+        for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+            assert a1 <= b0
     for x, q, sf in kept:
         ref = oc.uniform_quantize(x.numpy(), 16, 256)
         assert np.array_equal(host(q), ref['q'])
         assert np.array_equal(host(sf.alpha).reshape(-1), ref['alpha'].reshape(-1))
         assert np.array_equal(host(sf.beta).reshape(-1), ref['beta'].reshape(-1))
-        if '_ab_slab' in sf.__dict__:
-            slabs.add(sf._ab_slab.data_ptr())
-        else:
-            assert sf.alpha.numel() > (1 << 18) // 8          # the big ones were allocated on their own
-    assert len(slabs) >= 3, 'the sizes above fill more than two 1 MiB slabs'
-    # byte ranges carved from one slab are disjoint
-    by_slab = {}
-    for _, _, sf in kept:
-        if '_ab_slab' in sf.__dict__:
-            nb = sf.alpha.numel()
-            by_slab.setdefault(sf._ab_slab.data_ptr(), []).append((sf._ab_off, sf._ab_off + 2 * nb))
-    for ranges in by_slab.values():
-        ranges.sort()
-        for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
-            assert a1 <= b0
+        assert sf.__dict__.get('_ab_slab') is None            # read: the slab is released
 
 
 def test_slab_is_per_stream():
@@ -118,8 +119,8 @@ def test_slab_is_per_stream():
         q1, sf1 = quantization.uniformQuantization(x, 16, bucket_size=256)
     side.synchronize()
     torch.cuda.synchronize()
+    assert sf0._ab_slab.data_ptr() != sf1._ab_slab.data_ptr()          # (before the pairs are read: reading releases the slab)
     assert torch.equal(q0, q1) and torch.equal(sf0.alpha, sf1.alpha) and torch.equal(sf0.beta, sf1.beta)
-    assert sf0._ab_slab.data_ptr() != sf1._ab_slab.data_ptr()
 
 
 def test_everything_else_takes_the_general_path():
@@ -201,7 +202,7 @@ def test_retained_scaling_functions_do_not_pin_slabs():
     are first read and lets the slab go.  64 kept objects, each carved from a different slab: device memory held by them
     drops from 64 MiB to a few KiB once their alpha has been read."""
     torch.cuda.synchronize()
-    small = torch.randn(300, device=DEV)
+    small = torch.randn(200, device=DEV)
     filler = torch.randn(256 * 30000, device=DEV)            # 30000 buckets = 60000 floats: a fresh slab every 4 calls
     kept = []
     for i in range(64):

@@ -129,13 +129,13 @@ def test_point_gradient_vs_the_staged_reference_on_wrn_shapes():
         _, gp = fn.backward(g.to(DEV))
         rf = refq.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=t.clone())
         qr = rf.forward(None, pts.cpu())
-        assert np.array_equal(q.cpu().numpy(), qr.numpy()), (i, 'forward differs from the reference')
+        assert np.array_equal(q.cpu().numpy(), qr.cpu().numpy()), (i, 'forward differs from the reference')
         _, gpr = rf.backward(g.clone())
         want = oracle_c.nonuniform_quantize(t.numpy(), pts.cpu().numpy(), bucket, mode='midpoint')
         wg, absum = oracle_c.point_grad(g.numpy(), want['idx'], want['alpha'], bucket, k)
         tag = (i, tuple(t.shape))
-        errlog.check_sum("K6 vs the staged reference's own fp32 gradPointTensor, WRN-16-22 shapes", gp.cpu().numpy(), gpr.numpy(), absum,
+        errlog.check_sum("K6 vs the staged reference's own fp32 gradPointTensor, WRN-16-22 shapes", gp.cpu().numpy(), gpr.cpu().numpy(), absum,
                          tag, n_terms=t.numel())
         errlog.check_sum('K6 vs float64 oracle, WRN-16-22 shapes', gp.cpu().numpy(), wg, absum, tag, n_terms=t.numel())
-        errlog.check_sum("the staged reference's fp32 gradPointTensor vs float64 oracle, WRN-16-22 shapes", gpr.numpy(), wg, absum, tag,
+        errlog.check_sum("the staged reference's fp32 gradPointTensor vs float64 oracle, WRN-16-22 shapes", gpr.cpu().numpy(), wg, absum, tag,
                          n_terms=t.numel(), tol=1e-5)

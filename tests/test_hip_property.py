@@ -120,6 +120,7 @@ def test_ste_backward_matches_oracle(n, bucket, s, seed, kind):
     out = fn.backward(torch.from_numpy(g).to(DEV)).cpu().numpy()
     ref = oc.ste_complicated_backward(x, g, s, bucket)
     errlog.check_ste('K7 bucket sum, property soak', out, x, g, s, bucket, (n, bucket, s, seed, kind))
+    atol = 1e-6 * (np.abs(g).mean() + 1e-30) * min(bucket, n) + 1e-30          # "clearly visible" threshold below
     # tie rule: only the first arg-min / arg-max of each bucket of the QUANTIZED tensor may be touched.  (A
     # correction below half an ulp of g leaves g unchanged, and whether it does depends on the summation
     # order, so "touched" is compared as a subset plus the positions whose correction is clearly visible.)

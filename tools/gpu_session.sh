@@ -22,7 +22,7 @@ for step in "$@"; do
   case $step in
     stack)   (cat /opt/rocm/.info/version 2>/dev/null; python -c "import torch; print('torch', torch.__version__, 'hip', torch.version.hip, torch.cuda.get_device_name(0))"; rocminfo 2>/dev/null | grep -m3 -i "gfx\|Marketing"; nproc; lscpu | grep -m1 "Model name") > gpurun_out/stack.txt 2>&1; cat gpurun_out/stack.txt ;;
     smoke)   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log ;;
-    tests)   rm -f gpurun_out/reduction_error.jsonl; timeout 3000 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.log; python tools/summarize_reduction_error.py > gpurun_out/reduction_error.txt 2>&1; cat gpurun_out/reduction_error.txt ;;
+    tests)   rm -f gpurun_out/reduction_error.jsonl; timeout 3000 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.log; python tools/summarize_reduction_error.py > gpurun_out/reduction_error.txt 2>&1; cat gpurun_out/reduction_error.txt ;;
     bench)   timeout 1500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-900 gpurun_out/bench.json
              timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-distill 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('driver flags:', d['value'], d['roofline']['avg_launch_us'], d['roofline']['frac'])" ;;
     prof)    rm -rf gpurun_out/prof_stats gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
