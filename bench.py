@@ -137,11 +137,11 @@ def cpu_baseline(x_host, q_gpu, alpha_gpu):
     return out
 
 
-def cpu_distill_baseline(refq=None, steps=12, warmup=2, batch=50):
+def cpu_distill_baseline(refq=None, steps=200, warmup=3, batch=50):
     """BASELINE configs[0]: the CIFAR10 ConvolForwardNet student step on the CPU with the
     reference's own quantizer (staged bytecode; its torch-op port when nothing is staged) in the
-    reference's loop shape (quantize every parameter, fwd/bwd with the KD loss, restore, SGD) --
-    bounded sample."""
+    reference's loop shape (quantize every parameter, fwd/bwd with the KD loss, restore, SGD): the
+    200 steps of configs[0]'s "1 epoch synthetic" (10000 images / batch 50), ~25 s."""
     from harness import models
     from oracle.torch_port import uniform_quantize_torch_ops
     if refq is not None:
@@ -184,8 +184,9 @@ def cpu_distill_baseline(refq=None, steps=12, warmup=2, batch=50):
     return {'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2),
             'quantize_ms_per_step': round(t_quant / steps * 1e3, 3), 'threads': threads,
             'quantizer': 'reference (oracle/_ref bytecode)' if refq is not None else 'torch-op port (oracle/torch_port.py)',
-            'sample': '%d steps, batch %d, synthetic CIFAR10-shaped data; student+teacher fwd, KD loss, bwd, SGD on the '
-                      'host with the reference quantizer in the loop (configs[0])' % (steps, batch)}
+            'sample': '%d steps (one synthetic epoch: 10000 images) after %d warm-up steps, batch %d, synthetic CIFAR10-shaped '
+                      'data; student+teacher fwd, KD loss, bwd, SGD on the host with the reference quantizer in the loop '
+                      '(configs[0])' % (steps, warmup, batch)}
 
 
 def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, per_gpu_batch=50):
@@ -200,60 +201,75 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
     out = {'config': 'CIFAR10-shaped synthetic randn(B,3,32,32), ConvolForwardNet student (22 tensors, 1.00 M '
                      'params) distilled from the 5.3 M teacher, KD loss T=2, SGD nesterov, 4-bit uniform, bucket 256, STE',
            'per_gpu_batch': per_gpu_batch, 'global_batch': per_gpu_batch * n_gpus, 'steps': steps, 'warmup': warmup}
-    for mode in ('multi', 'per_tensor'):
-        tr = DistillTrainer(models.student(), models.teacher(), dev, num_bits=4, bucket_size=256,
-                            mode='multi' if mode == 'multi_graph' else mode)
-        batches = [synthetic_batch(per_gpu_batch, dev, seed=1000 * rank + i) for i in range(4)]
-        if mode == 'multi_graph':
-            try:
-                tr.capture(*batches[0])
-            except Exception as e:                         # noqa: BLE001 -- report, do not hide
-                out[mode] = {'error': 'graph capture failed: %r' % (e,)}
-                del tr
-                continue
+    import statistics
+    modes = ('multi', 'per_tensor')
+    batches = [synthetic_batch(per_gpu_batch, dev, seed=1000 * rank + i) for i in range(4)]
+    trainers = {}
+    for mode in modes:
+        torch.manual_seed(0)
+        trainers[mode] = DistillTrainer(models.student(), models.teacher(), dev, num_bits=4, bucket_size=256, mode=mode)
         for i in range(warmup):
+            trainers[mode].step(*batches[i % 4])
+
+    def timed_repetition(tr):
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
             tr.step(*batches[i % 4])
-        # the 2 ms step is bound by MIOpen's small-shape convolutions and moves by +-15 % between repetitions on one box
-        # (tools/distill_order_probe.py): three timed repetitions of `steps`, the fastest one is reported, all are listed
-        reps = []
-        for _rep in range(3):
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
             torch.cuda.synchronize()
-            if distributed:
-                dist.barrier()
-                torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                tr.step(*batches[i % 4])
-            torch.cuda.synchronize()
-            if distributed:
-                dist.barrier()
-                torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            if distributed:
-                t = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t[0])
-            reps.append(dt)
-        dt = min(reps)
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return dt
+
+    # The 2 ms step is ~150 small launches (MIOpen's small-shape convolutions, batch-norm, the optimizer) and its time
+    # moves from repetition to repetition on one box (profiles/r03_distill_spread.txt).  So: REPS repetitions of `steps`
+    # steps per mode, INTERLEAVED (multi, per_tensor, multi, ...) so that drift hits both alike; the MEDIAN is reported,
+    # every repetition is listed, and the two modes are only called different when their ranges do not overlap.
+    REPS = 7
+    reps = {m: [] for m in modes}
+    for _rep in range(REPS):
+        for mode in modes:
+            reps[mode].append(timed_repetition(trainers[mode]))
+    for mode in modes:
+        tr = trainers[mode]
+        dt = statistics.median(reps[mode])
         # per-phase breakdown (each phase bracketed by synchronize; serialised, so the sum exceeds the step)
         phases = {}
-        def timed(name, fn, reps=20):
+
+        def timed(name, fn, nrep=20):
             torch.cuda.synchronize()
             a = time.perf_counter()
-            for _ in range(reps):
+            for _ in range(nrep):
                 fn()
             torch.cuda.synchronize()
-            phases[name] = round((time.perf_counter() - a) / reps * 1e3, 4)
+            phases[name] = round((time.perf_counter() - a) / nrep * 1e3, 4)
         x, y = batches[0]
         timed('quantize_ms', tr.quantize)
         timed('fwd_bwd_ms', lambda: tr.forward_backward(x, y))
         timed('restore_ms', tr.restore)
         timed('allreduce_ms', tr.sync.sync)
         timed('optimizer_ms', tr.opt.step)
+        sps = sorted(steps / r for r in reps[mode])
         out[mode] = {'steps_per_sec': round(steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
-                     'samples_per_sec': round(steps * per_gpu_batch * n_gpus / dt, 1),
-                     'steps_per_sec_repetitions': [round(steps / r, 1) for r in reps], 'phases': phases}
-        del tr
+                     'samples_per_sec': round(steps * per_gpu_batch * n_gpus / dt, 1), 'statistic': 'median of %d repetitions' % REPS,
+                     'steps_per_sec_min': round(sps[0], 1), 'steps_per_sec_max': round(sps[-1], 1),
+                     'steps_per_sec_repetitions': [round(steps / r, 1) for r in reps[mode]], 'phases': phases}
+    lo_m, hi_m = out['multi']['steps_per_sec_min'], out['multi']['steps_per_sec_max']
+    lo_p, hi_p = out['per_tensor']['steps_per_sec_min'], out['per_tensor']['steps_per_sec_max']
+    out['multi_vs_per_tensor'] = ('multi faster in every repetition' if lo_m > hi_p else
+                                  'per_tensor faster in every repetition' if lo_p > hi_m else
+                                  'indistinguishable: the repetition ranges overlap (the quantizer is %.3f / %.3f ms of the step)'
+                                  % (out['multi']['phases']['quantize_ms'], out['per_tensor']['phases']['quantize_ms']))
+    trainers.clear()
     out['note'] = ("'multi' = one multi-tensor quantize launch per step on persistent shadows (K9); 'per_tensor' = the "
                    "reference's loop shape (22 uniformQuantization calls + restore).  hipGraph replay of the step "
                    "(DistillTrainer.capture) measured no gain: the step is bound by MIOpen's small-shape conv kernels, "

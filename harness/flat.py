@@ -37,10 +37,11 @@ def force_collectives():
 
 
 class GradSynchronizer(object):
-    """Data-parallel gradient exchange: all-reduce (sum) of the flat fp32 gradient buffer, then a
-    scale by 1/world -- the MI355X-native stand-in for nn.DataParallel's reduce-to-GPU0 +
-    broadcast (ref: resnet34_doublefilters.py:69-70,81-82, translation_models/model.py:47-48).
-    Over RCCL/xGMI on GPUs ("nccl" backend), over gloo in the CPU tests.
+    """Data-parallel gradient exchange: all-reduce (MEAN) of the flat fp32 gradient buffer -- the MI355X-native stand-in
+    for nn.DataParallel's reduce-to-GPU0 + broadcast (ref: resnet34_doublefilters.py:69-70,81-82,
+    translation_models/model.py:47-48).  Over RCCL/xGMI on GPUs ("nccl" backend): ReduceOp.AVG, the 1/world folded into
+    the collective (a separate scaling pass over a 103-331 MB gradient buffer is a full extra read + write of HBM);
+    over gloo in the CPU tests, which has no AVG: sum, then scale.
 
     chunks == 1: ONE all-reduce of the whole buffer after backward (small models).
     chunks  > 1 without attach(): the buffer is cut into `chunks` equal pieces, all launched
@@ -64,6 +65,7 @@ class GradSynchronizer(object):
         self.world = dist.get_world_size(group) if ready else 1
         force = force_collectives() if force is None else force
         self.active = ready and (self.world > 1 or force)
+        self._avg = bool(ready and dist.get_backend(group) == 'nccl')     # RCCL reduces to the mean itself
         n = flat_grad.numel()
         self.chunks = max(1, min(chunks, n))
         step = -(-n // self.chunks)
@@ -140,7 +142,8 @@ class GradSynchronizer(object):
 
     def _all_reduce_async(self, a, b):
         self.collectives_issued += 1
-        return dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM,
+                               group=self.group, async_op=True)
 
     def _launch(self, c):
         for a, b in self._group_ranges[c]:
@@ -167,7 +170,7 @@ class GradSynchronizer(object):
         if self._group_of is not None:
             self._pending = list(self._group_sizes)
             self._launched = [False] * len(self._group_ranges)
-        if self.world > 1:
+        if self.world > 1 and not self._avg:
             self.flat_grad.mul_(1.0 / self.world)
 
 
