@@ -414,6 +414,68 @@ def load_pmc_traffic():
         return None
 
 
+def pmc_slice():
+    """Child of measure_pmc_traffic(): a dozen launches of the headline call under rocprofv3, nothing else."""
+    import quantization
+    dev = torch.device('cuda', 0)
+    gen = torch.Generator().manual_seed(0)
+    xs = [torch.randn(N_ELEM, generator=gen).to(dev) for _ in range(2)]
+    live = [None, None]
+    for i in range(12):
+        live[i % 2] = quantization.uniformQuantization(xs[i % 2], LEVELS, bucket_size=BUCKET)[0]
+    torch.cuda.synchronize()
+
+
+def measure_pmc_traffic(timeout_s=150):
+    """HBM bytes per launch of the headline kernel MEASURED IN THIS RUN: two short rocprofv3 passes (--pmc FETCH_SIZE, then
+    --pmc WRITE_SIZE, each with --kernel-trace only, as MI355X_MICROARCH.md prescribes: the two counters do not fit one
+    pass) over a 12-launch slice of the same call in a child process, after the timed region.  FETCH_SIZE / WRITE_SIZE
+    are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced streaming read, so read bytes = 2 x FETCH_SIZE x 1024
+    (the guide's correction).  Returns a dict; on any failure {'error': ...} -- the headline number never depends on it."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return {'error': 'rocprofv3 not found'}
+    raw = {}
+    t_start = time.time()
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        with tempfile.TemporaryDirectory(dir='/tmp') as td:
+            env = dict(os.environ, TMPDIR='/tmp')
+            for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'QD_FORCE_DIST'):
+                env.pop(k, None)
+            cmd = [exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', td, '-o', 'pmc', '--',
+                   sys.executable, os.path.abspath(__file__), '--pmc-slice']
+            try:
+                r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return {'error': 'rocprofv3 --pmc %s timed out after %d s' % (counter, timeout_s)}
+            files = glob.glob(os.path.join(td, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return {'error': 'rocprofv3 --pmc %s: rc %d, %d counter files; %s'
+                                 % (counter, r.returncode, len(files), r.stderr.decode(errors='replace')[-300:])}
+            vals = {}
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if 'k_bucket_vec' in row.get('Kernel_Name', '') and row.get('Counter_Name') == counter:
+                        vals[int(row['Dispatch_Id'])] = vals.get(int(row['Dispatch_Id']), 0.0) + float(row['Counter_Value'])
+            v = [vals[k] for k in sorted(vals)][2:]                       # drop the first two launches
+            if not v:
+                return {'error': 'no k_bucket_vec dispatch in the %s pass' % counter}
+            raw[counter] = {'per_launch_KiB_avg': sum(v) / len(v), 'launches': len(v), 'min': min(v), 'max': max(v)}
+    read_b = 2.0 * raw['FETCH_SIZE']['per_launch_KiB_avg'] * 1024
+    write_b = raw['WRITE_SIZE']['per_launch_KiB_avg'] * 1024
+    algo = ALGO_BYTES_PER_ELEM * N_ELEM
+    return {'bytes_per_launch': round(read_b + write_b), 'read_bytes_per_launch': round(read_b), 'write_bytes_per_launch': round(write_b),
+            'over_algorithmic': round((read_b + write_b) / algo, 4), 'raw_KiB': raw, 'seconds': round(time.time() - t_start, 1),
+            'how': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace over 12 launches of the headline call in '
+                   'a child process of this run; read = 2 x FETCH_SIZE x 1024 (gfx950 halves wide streaming reads), '
+                   'write = WRITE_SIZE x 1024'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -424,7 +486,12 @@ def main():
     ap.add_argument('--no-diffquant', action='store_true', help='skip the WideResNet differentiable-quantization leg')
     ap.add_argument('--no-dp-configs', action='store_true', help='skip the ImageNet-shaped and seq2seq steps/sec legs')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 PMC passes that measure the HBM traffic of the headline kernel')
+    ap.add_argument('--pmc-slice', action='store_true', help=argparse.SUPPRESS)       # child mode of measure_pmc_traffic()
     args = ap.parse_args()
+    if args.pmc_slice:
+        pmc_slice()
+        return
 
     from harness import launch
     if args.gpus > 1 and not launch.under_launcher():
@@ -545,6 +612,14 @@ def main():
     torch.cuda.synchronize()
     copy_gbps = ALGO_BYTES_PER_ELEM * N_ELEM * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
+    # HBM traffic of the headline kernel, measured now (rank 0, N=1; after the timed regions, in a child process)
+    traffic_measured = None
+    if rank == 0 and n_gpus == 1 and not args.no_pmc:
+        try:
+            traffic_measured = measure_pmc_traffic()
+        except Exception as e:                                    # noqa: BLE001
+            traffic_measured = {'error': '%s: %s' % (type(e).__name__, e)}
+
     # cpu_baseline leg (rank 0, N=1 only): the oracle is timed on the host cores and, in the same leg,
     # used as the checker of the GPU result computed above (bit-exact comparison)
     parity = None
@@ -621,9 +696,12 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'k_bucket_vec<MODE_QDQ,16,4>',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': load_pmc_traffic(),
-                'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on a '
-                                  'builder box (committed file, NOT measured in this run)',
+                'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                'traffic': (traffic_measured or {}).get('bytes_per_launch') or load_pmc_traffic(),
+                'traffic_source': ('measured in this run (traffic_measured)' if (traffic_measured or {}).get('bytes_per_launch') else
+                                   'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on a '
+                                   'builder box (committed file, NOT measured in this run)'),
+                'traffic_measured': traffic_measured, 'traffic_committed': load_pmc_traffic(),
                 'extended': {'launches': ext_n, 'avg_launch_us': round(ext_us, 3),
                              'frac': round(bytes_per_launch / (ext_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)},
                 'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
