@@ -342,4 +342,29 @@ __device__ __forceinline__ int count_before(const float* a, int n, float u) {
     return lo;
 }
 
+// Four searches at once over the same sorted array: the same uniform trip count, but the four LDS reads of a step are
+// independent -- one LDS round trip per step and float4 instead of four dependent chains one after the other.  (A kernel
+// that holds several float4s per lane at two or three waves per SIMD cannot hide those chains behind other waves: the
+// pre-processed forward at bucket 100 ran at 145 us against 94 us for the same kernel without the point search.)
+template <bool UPPER>
+__device__ __forceinline__ void count_before4(const float* a, int n, const float (&u)[4], int (&lo)[4]) {
+    lo[0] = 0; lo[1] = 0; lo[2] = 0; lo[3] = 0;
+    while (n > 1) {
+        const int half = n >> 1;
+        const float v0 = a[lo[0] + half - 1], v1 = a[lo[1] + half - 1], v2 = a[lo[2] + half - 1], v3 = a[lo[3] + half - 1];
+        lo[0] += (UPPER ? (v0 <= u[0]) : (v0 < u[0])) ? half : 0;
+        lo[1] += (UPPER ? (v1 <= u[1]) : (v1 < u[1])) ? half : 0;
+        lo[2] += (UPPER ? (v2 <= u[2]) : (v2 < u[2])) ? half : 0;
+        lo[3] += (UPPER ? (v3 <= u[3]) : (v3 < u[3])) ? half : 0;
+        n -= half;
+    }
+    if (n == 1) {
+        const float v0 = a[lo[0]], v1 = a[lo[1]], v2 = a[lo[2]], v3 = a[lo[3]];
+        lo[0] += (UPPER ? (v0 <= u[0]) : (v0 < u[0])) ? 1 : 0;
+        lo[1] += (UPPER ? (v1 <= u[1]) : (v1 < u[1])) ? 1 : 0;
+        lo[2] += (UPPER ? (v2 <= u[2]) : (v2 < u[2])) ? 1 : 0;
+        lo[3] += (UPPER ? (v3 <= u[3]) : (v3 < u[3])) ? 1 : 0;
+    }
+}
+
 }  // namespace qd

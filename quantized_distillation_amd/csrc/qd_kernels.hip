@@ -70,11 +70,30 @@ struct KParams {
 // LDS-resident point table (+ midpoints, quant_functions.py:533)
 constexpr int kCells = 256;             // uniform grid over [0,1] that narrows the midpoint search (k > 32)
 
+// The table lives at the START of the kernel's dynamic LDS (every nearest-point launch asks for point_table_bytes(k) more),
+// sized by the number of points: 256 bytes up to 32 points -- every configuration of the reference's scripts -- instead of
+// a static 10.3 KB for the 1024 points the ABI allows.  (The static table left the chunk kernels 6 / 5 blocks per CU, bound
+// by LDS; the point search is a chain of dependent LDS reads, so resident waves are what hides it.)
+struct PointStore {
+    float* pts;                         // [cap]
+    float* mid;                         // [cap]
+    int* start;                         // [kCells + 4], k > 32 only: start[c] = #{ j : cell(mid_j) < c }, c = 0..kCells
+    int* startp;                        // same for the points themselves (distance rule)
+};
+extern __shared__ __attribute__((aligned(16))) unsigned char qd_dyn_lds[];     // every kernel's dynamic LDS starts here
+constexpr int kSmallTable = 32;
+__host__ __device__ constexpr size_t point_table_bytes(int k) {
+    return k <= kSmallTable ? (size_t)2 * kSmallTable * sizeof(float)
+                            : (size_t)2 * kMaxPoints * sizeof(float) + (size_t)2 * (kCells + 4) * sizeof(int);
+}
+
+// What the kernels pass around: a handle on the LDS table.  (Tried in round 3 and dropped: for k <= 8 the points and
+// midpoints themselves in wave-uniform registers, the assignment as k - 1 compares and selects without any LDS access.
+// 23 more live scalar values pushed the kernels' SGPR use over the limit (88-179 SGPR spills into VGPR lanes) and the
+// pre-processed forward got SLOWER at every bucket size: k = 4, bucket 256 / 100 / 1000: 107 / 192 / 130 us against
+// 93 / 114 / 97 us with the joint LDS search of count_before4 -- profiles/r03_side_outputs.txt.)
 struct PointTable {
-    float pts[kMaxPoints];
-    float mid[kMaxPoints];
-    int start[kCells + 4];              // start[c] = #{ j : cell(mid_j) < c }, c = 0..kCells
-    int startp[kCells + 4];             // same for the points themselves (distance rule)
+    const PointStore* s;
 };
 
 // cell of a scaled value: monotone non-decreasing in u (x256 is exact in fp32, then truncation and a
@@ -85,7 +104,12 @@ __device__ __forceinline__ int cell_of(float u) {
     return c < kCells - 1 ? c : kCells - 1;
 }
 
-__device__ __forceinline__ void load_points(PointTable& T, const float* pts, int k) {
+__device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const float* pts, int k) {
+    const int cap = k <= kSmallTable ? kSmallTable : kMaxPoints;
+    T.pts = (float*)qd_dyn_lds;
+    T.mid = T.pts + cap;
+    T.start = (int*)(T.mid + cap);
+    T.startp = T.start + (kCells + 4);
     for (int j = threadIdx.x; j < k; j += blockDim.x) T.pts[j] = pts[j];
     __syncthreads();
     for (int j = threadIdx.x; j + 1 < k; j += blockDim.x) {
@@ -112,6 +136,7 @@ __device__ __forceinline__ void load_points(PointTable& T, const float* pts, int
         }
         __syncthreads();
     }
+    C.s = &T;
 }
 
 // #{ midpoints <= u }.  For many points the search is narrowed to the midpoints that fall in u's
@@ -119,7 +144,7 @@ __device__ __forceinline__ void load_points(PointTable& T, const float* pts, int
 // is monotone), so the count is exact whatever the point distribution; with roughly uniform points
 // the remaining range holds 0-2 midpoints instead of k-1 (LDS reads per element: ~4 instead of ~9
 // at k = 256, and fewer bank conflicts).
-__device__ __forceinline__ int midpoint_index(const PointTable& T, int k, float u) {
+__device__ __forceinline__ int midpoint_index(const PointStore& T, int k, float u) {
     if (k <= 32) return count_before<true>(T.mid, k - 1, u);
     const int c = cell_of(u);
     const int s0 = T.start[c];
@@ -127,7 +152,7 @@ __device__ __forceinline__ int midpoint_index(const PointTable& T, int k, float 
 }
 
 // nearest point of u (quant_functions.py:267-273 or :531-573)
-__device__ __forceinline__ int assign_point(const PointTable& T, int k, int mode, float u) {
+__device__ __forceinline__ int assign_point(const PointStore& T, int k, int mode, float u) {
     if (mode == QD_ASSIGN_MIDPOINT) return midpoint_index(T, k, u);
     int i;                                           // searchsorted(side='left'): #{ points < u }
     if (k <= 32) {
@@ -162,13 +187,82 @@ __device__ __forceinline__ float transform(const KParams& p, const PointTable* T
     } else {
         float u = v;
         if (!p.prescaled) { u = v - b; u = u / a; }
-        const int i = assign_point(*T, p.k, p.assign_mode, u);
+        const int i = assign_point(*T->s, p.k, p.assign_mode, u);
+        const float pt = T->s->pts[i];
         side = (float)i;
-        float y = T->pts[i] * a;
+        float y = pt * a;
         y = y + b;
         y = y + mean;
         return y;
     }
+}
+
+// nearest points of the four elements of a float4.  Up to 32 points (every configuration of the reference's scripts:
+// 2^bits points, bits <= 4 in the differentiable-quantization runs): the four searches advance together
+// (count_before4); above that each element narrows its own search to its grid cell as assign_point does.
+__device__ __forceinline__ void assign_point4(const PointStore& T, int k, int mode, const float (&u)[4], int (&i)[4]) {
+    if (k > 32) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) i[c] = assign_point(T, k, mode, u[c]);
+        return;
+    }
+    if (mode == QD_ASSIGN_MIDPOINT) {
+        count_before4<true>(T.mid, k - 1, u, i);
+        return;
+    }
+    count_before4<false>(T.pts, k, u, i);                // searchsorted(side='left'): #{ points < u }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) i[c] = i[c] > k - 1 ? k - 1 : i[c];                 // .clip(max=k-1)
+    float pl[4], ph[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pl[c] = T.pts[i[c] > 0 ? i[c] - 1 : 0]; ph[c] = T.pts[i[c]]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float dl = fabsf(u[c] - pl[c]);
+        const float dh = fabsf(u[c] - ph[c]);
+        i[c] -= (i[c] > 0 && dl < dh) ? 1 : 0;           // strictly closer to the lower point
+    }
+}
+
+// transform<MODE>() of the four elements of a float4 that share (a, b): the same arithmetic per element; in the
+// nearest-point mode the four point searches run together.
+template <int MODE, bool FAST = false>
+__device__ __forceinline__ void transform_x4(const KParams& p, const PointTable* T, const float (&v)[4], float a, float b,
+                                             float mean, const float (&rnd)[4], float (&side)[4], float (&out)[4],
+                                             float y = 0.0f) {
+    if (MODE == MODE_NEAREST) {
+        float u[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u[c] = v[c];
+            if (!p.prescaled) { u[c] = v[c] - b; u[c] = u[c] / a; }
+        }
+        int i[4];
+        float pt[4];
+        assign_point4(*T->s, p.k, p.assign_mode, u, i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pt[c] = T->s->pts[i[c]];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            side[c] = (float)i[c];
+            float o = pt[c] * a;
+            o = o + b;
+            o = o + mean;
+            out[c] = o;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = transform<MODE, FAST>(p, T, v[c], a, b, mean, rnd[c], side[c], y);
+    }
+}
+template <int MODE, bool FAST = false>
+__device__ __forceinline__ f4 transform_f4(const KParams& p, const PointTable* T, const f4& v, float a, float b, float mean,
+                                           const float (&rnd)[4], float (&side)[4], float y = 0.0f) {
+    const float xs[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+    transform_x4<MODE, FAST>(p, T, xs, a, b, mean, rnd, side, o, y);
+    const f4 r = {o[0], o[1], o[2], o[3]};
+    return r;
 }
 
 template <int MODE>
@@ -329,11 +423,7 @@ __device__ __forceinline__ void bucket_lanes4(const KParams& p, const PointTable
             }
         }
         float side[4];
-        f4 r;
-        r.x = transform<MODE>(p, T, v.x, a, b, pp.mean, rnd[0], side[0]);
-        r.y = transform<MODE>(p, T, v.y, a, b, pp.mean, rnd[1], side[1]);
-        r.z = transform<MODE>(p, T, v.z, a, b, pp.mean, rnd[2], side[2]);
-        r.w = transform<MODE>(p, T, v.w, a, b, pp.mean, rnd[3], side[3]);
+        const f4 r = transform_f4<MODE>(p, T, v, a, b, pp.mean, rnd, side);
         __builtin_nontemporal_store(r, dst + i);
         for (int c = 0; c < 4; ++c) store_side1<MODE>(p, e + c, side[c]);
     }
@@ -415,10 +505,7 @@ __device__ __forceinline__ void vec_apply(const KParams& p, const PointTable* T,
             r.z = qdq_stochastic_tab<FAST>(v[j].z, a, b, p.sm1, pp.mean, rnd[2], side[2], fl.tab, y);
             r.w = qdq_stochastic_tab<FAST>(v[j].w, a, b, p.sm1, pp.mean, rnd[3], side[3], fl.tab, y);
         } else {
-            r.x = transform<MODE, FAST>(p, T, v[j].x, a, b, pp.mean, rnd[0], side[0], y);
-            r.y = transform<MODE, FAST>(p, T, v[j].y, a, b, pp.mean, rnd[1], side[1], y);
-            r.z = transform<MODE, FAST>(p, T, v[j].z, a, b, pp.mean, rnd[2], side[2], y);
-            r.w = transform<MODE, FAST>(p, T, v[j].w, a, b, pp.mean, rnd[3], side[3], y);
+            r = transform_f4<MODE, FAST>(p, T, v[j], a, b, pp.mean, rnd, side, y);
         }
         __builtin_nontemporal_store(r, dst + j * LPB);
         store_side4_row<MODE>(p, e, side);
@@ -467,9 +554,10 @@ __device__ __forceinline__ void vec_bucket(const KParams& p, const PointTable* T
 
 template <int MODE, int LPB, int V, int U>
 __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
-    __shared__ PointTable Ts;
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    PointStore Ts;
+    PointTable Tc;
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
 
     constexpr int BPW = (64 / LPB) * U;           // buckets per wave tile
     constexpr int ROW = LPB * V * 4;              // elements per bucket
@@ -547,10 +635,12 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
 template <int MODE, int VMAX>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4)))   // the chunk lives in registers
 void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
-    __shared__ PointTable Ts;
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
-    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: pairs[VMAX * 64], ab[256], 1/alpha[256]
+    PointStore Ts;
+    PointTable Tc;
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    // dynamic LDS: [point table (nearest-point mode)] then per wave: pairs[VMAX * 64], ab[256], 1/alpha[256]
+    float2* chunk_lds = (float2*)(qd_dyn_lds + (MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float2* pr = chunk_lds + w * (VMAX * 64 + 256 + 128);
     float2* ab = pr + VMAX * 64;
@@ -652,12 +742,15 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
                     } else {
                         float rnd[4] = {0.f, 0.f, 0.f, 0.f};
                         if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
-                        o.x = transform<MODE, FAST>(p, T, v[j].x, s.x, s.y, pp.mean, rnd[0], side[0], y);
-                        o.y = transform<MODE, FAST>(p, T, v[j].y, s.x, s.y, pp.mean, rnd[1], side[1], y);
-                        o.z = transform<MODE, FAST>(p, T, v[j].z, s.x, s.y, pp.mean, rnd[2], side[2], y);
-                        o.w = transform<MODE, FAST>(p, T, v[j].w, s.x, s.y, pp.mean, rnd[3], side[3], y);
+                        o = transform_f4<MODE, FAST>(p, T, v[j], s.x, s.y, pp.mean, rnd, side, y);
                     }
-                    if (f < nf) {
+                    // (int64 indices: exchanged inside the DPP row -- 16 consecutive float4s, all in range -- so that each store
+                    // instruction writes 256 contiguous bytes; the row that straddles the end of the chunk stores per lane)
+                    const bool row_in = MODE == MODE_NEAREST && !group_any<16>(f >= nf);
+                    if (MODE == MODE_NEAREST && row_in) {
+                        __builtin_nontemporal_store(o, dst + f);
+                        store_side4_row<MODE>(p, e, side);
+                    } else if (f < nf) {
                         __builtin_nontemporal_store(o, dst + f);
                         store_side4<MODE>(p, e, side);
                     }
@@ -697,12 +790,21 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
 template <int MODE, int VMAX>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 6)))
 void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
-    __shared__ PointTable Ts;
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
-    extern __shared__ __attribute__((aligned(16))) float2 chunk_lds[];   // per wave: vals[VMAX * 256] floats
+    PointStore Ts;
+    PointTable Tc;
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    // dynamic LDS: [point table (nearest-point mode)] then per wave: vals[VMAX * 256] floats (+ side bytes)
+    float2* chunk_lds = (float2*)(qd_dyn_lds + (MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float* vals = (float*)(chunk_lds + w * (VMAX * 128));
+    // Side outputs (level / point indices up to 255) are staged as ONE BYTE per element behind the values -- a quarter more
+    // LDS, only when such an output is asked for -- and leave with the values: four per lane, coalesced.  Stored from the
+    // transform loop they would leave element by element in LDS order (lanes a bucket apart): 216 us instead of 95 us for
+    // quantize + levels at bucket 33, 405 us for int64 point indices (profiles/r03_side_outputs.txt).
+    const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 256);
+    const int wave_floats = VMAX * 256 + (stage8 ? VMAX * 64 : 0);
+    float* vals = (float*)chunk_lds + w * wave_floats;
+    uint8_t* sidev = (uint8_t*)(vals + VMAX * 256);
 
     const int B = (int)p.row;
     const int nf = (m * B) >> 2;                       // float4 per chunk (m % 4 == 0)
@@ -785,28 +887,44 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
             auto body = [&](auto fast_c) {
                 constexpr bool FAST = decltype(fast_c)::value;
                 const float y = FAST ? 1.0f / a : 0.0f; // RN(1/alpha), one IEEE division per bucket
-#pragma unroll 4
-                for (int i = 0; i < steps; ++i) {
-                    const int t_raw = sub + i * G;
-                    const bool ok = live && t_raw < B;
-                    const int t = t_raw < B ? t_raw : B - 1;
-                    const float x = q[t];
-                    const int64_t e = eb + t;
-                    float side = 0.0f, o;
-                    if (use_tab) {
-                        o = qdq_tab<FAST>(x, a, b, p.sm1, pp.mean, side, tab, y);
-                    } else {
-                        float rnd = 0.0f;
-                        if (MODE == MODE_QDQ && p.stochastic) {
-                            float r4[4];
-                            philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
-                            rnd = r4[e & 3];
-                        }
-                        o = transform<MODE, FAST>(p, T, x, a, b, pp.mean, rnd, side, y);
+                // four steps at a time: the four LDS reads, and in the nearest-point mode the four point searches, are
+                // independent of each other (one element per step left every lane with `steps` dependent LDS chains in a
+                // row: 234 us for the pre-processed forward at bucket 33 against 95 us for the plain quantize)
+                for (int i = 0; i < steps; i += 4) {
+                    int tt[4];
+                    bool ok[4];
+                    float xv[4], o[4], side[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int t_raw = sub + (i + c) * G;
+                        ok[c] = live && t_raw < B && i + c < steps;
+                        tt[c] = t_raw < B ? t_raw : B - 1;
                     }
-                    if (ok) {
-                        q[t] = o;
-                        store_side1<MODE>(p, e, side);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] = q[tt[c]];
+                    if (use_tab) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = qdq_tab<FAST>(xv[c], a, b, p.sm1, pp.mean, side[c], tab, y);
+                    } else {
+                        float rnd[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (MODE == MODE_QDQ && p.stochastic) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int64_t e = eb + tt[c];
+                                float r4[4];
+                                philox_uniform4(p.seed, (uint64_t)e >> 2, r4);
+                                rnd[c] = r4[e & 3];
+                            }
+                        }
+                        transform_x4<MODE, FAST>(p, T, xv, a, b, pp.mean, rnd, side, o, y);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (ok[c]) {
+                            q[tt[c]] = o[c];
+                            if (stage8) sidev[bb * B + tt[c]] = (uint8_t)(int)side[c];
+                            else store_side1<MODE>(p, eb + tt[c], side[c]);
+                        }
                     }
                 }
             };
@@ -818,7 +936,22 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
 #pragma unroll
         for (int j = 0; j < VMAX; ++j) {
             const int f = lane + 64 * j - h;
-            if (f >= 0 && f < nf) __builtin_nontemporal_store(((const f4*)vals)[f], dst + f);
+            const bool in = f >= 0 && f < nf;
+            if (in) __builtin_nontemporal_store(((const f4*)vals)[f], dst + f);
+            if (MODE != MODE_SCALE && stage8) {
+                const uint32_t pk = in ? ((const uint32_t*)sidev)[f] : 0u;
+                const int64_t e = e0 + ((int64_t)f << 2);
+                if (MODE == MODE_QDQ) {
+                    if (in) *(uint32_t*)(p.lev8 + e) = pk;
+                } else if (p.idx_bytes == 1) {
+                    if (in) *(uint32_t*)((uint8_t*)p.idx + e) = pk;
+                } else {
+                    // int64: through the DPP-row exchange where the row's 16 float4s are all inside the chunk
+                    const float sd[4] = {(float)(pk & 255u), (float)((pk >> 8) & 255u), (float)((pk >> 16) & 255u), (float)(pk >> 24)};
+                    if (!group_any<16>(!in)) store_side4_row<MODE>(p, e, sd);
+                    else if (in) store_side4<MODE>(p, e, sd);
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next chunk overwrites vals
         __builtin_amdgcn_wave_barrier();
@@ -845,10 +978,11 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
 template <int MODE, int V, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))   // <= 256 VGPRs: the 32-float4 instance must keep two waves per SIMD
 void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
-    __shared__ PointTable Ts;
+    PointStore Ts;
+    PointTable Tc;
     __shared__ float red[2][4][2];                         // [iteration parity][wave of the block][min, max]
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
     constexpr int GL = 64 * G;                             // lanes per bucket
     constexpr int GPB = 4 / G;                             // buckets per block and iteration
     const int lane = threadIdx.x & (GL - 1);               // lane inside the bucket's group
@@ -961,10 +1095,8 @@ void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
                     float rnd[4] = {0.f, 0.f, 0.f, 0.f};
                     if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)e >> 2, rnd);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        side[c] = 0.0f;
-                        o[c] = transform<MODE, FAST>(p, T, xs[c], a, b, pp.mean, rnd[c], side[c], y);
-                    }
+                    for (int c = 0; c < 4; ++c) side[c] = 0.0f;
+                    transform_x4<MODE, FAST>(p, T, xs, a, b, pp.mean, rnd, side, o, y);
                 }
                 if (off + 4 * GL * j >= 0 && off + 4 * GL * (j + 1) <= row) {   // group-uniform: the whole round is inside the bucket
                     const f4 r = {o[0], o[1], o[2], o[3]};
@@ -1003,9 +1135,10 @@ void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
 // blocks, no LDS, no barrier.  Any row length / alignment.
 template <int MODE, int LANES>
 __global__ __launch_bounds__(256) void k_bucket_groups(KParams p) {
-    __shared__ PointTable Ts;
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    PointStore Ts;
+    PointTable Tc;
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -1024,10 +1157,11 @@ __global__ __launch_bounds__(256) void k_bucket_groups(KParams p) {
 // ---- generic path, huge rows: one block per bucket, any row length / alignment ----------------
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_bucket_generic(KParams p) {
-    __shared__ PointTable Ts;
+    PointStore Ts;
+    PointTable Tc;
     __shared__ float red[32];
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -1146,10 +1280,11 @@ __global__ __launch_bounds__(256) void k_minmax_final(const float* part, int npa
 // launch fewer for the model-sized tensors, where the call is launch-bound, not bandwidth-bound.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab, const float* part, int nparts) {
-    __shared__ PointTable Ts;
+    PointStore Ts;
+    PointTable Tc;
     __shared__ float red[32];
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -1187,11 +1322,7 @@ __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab
             float rnd[4] = {0.f, 0.f, 0.f, 0.f};
             if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)i, rnd);
             float side[4];
-            f4 r;
-            r.x = transform<MODE>(p, T, v.x, a, b, pp.mean, rnd[0], side[0]);
-            r.y = transform<MODE>(p, T, v.y, a, b, pp.mean, rnd[1], side[1]);
-            r.z = transform<MODE>(p, T, v.z, a, b, pp.mean, rnd[2], side[2]);
-            r.w = transform<MODE>(p, T, v.w, a, b, pp.mean, rnd[3], side[3]);
+            const f4 r = transform_f4<MODE>(p, T, v, a, b, pp.mean, rnd, side);
             __builtin_nontemporal_store(r, o4 + i);
             store_side4<MODE>(p, i << 2, side);
         }
@@ -1270,12 +1401,7 @@ __device__ __forceinline__ f4 transform4(const KParams& p, const PointTable* T, 
                                          int64_t i4, float (&side)[4]) {
     float rnd[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == MODE_QDQ && p.stochastic) philox_uniform4(p.seed, (uint64_t)i4, rnd);
-    f4 r;
-    r.x = transform<MODE>(p, T, v.x, a, b, mean, rnd[0], side[0]);
-    r.y = transform<MODE>(p, T, v.y, a, b, mean, rnd[1], side[1]);
-    r.z = transform<MODE>(p, T, v.z, a, b, mean, rnd[2], side[2]);
-    r.w = transform<MODE>(p, T, v.w, a, b, mean, rnd[3], side[3]);
-    return r;
+    return transform_f4<MODE>(p, T, v, a, b, mean, rnd, side);
 }
 
 // One sweep over the G slots (all threads of the block): true when every slot carries this launch's epoch; then
@@ -1304,11 +1430,12 @@ __device__ __forceinline__ bool sweep_slots(const FusedCtl* ctl, unsigned G, uns
 template <int MODE, int V, int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
 void k_single_fused(KParams p, int slot_set, unsigned tag_min, unsigned tag_max, int give_up_mode) {
-    __shared__ PointTable Ts;
+    PointStore Ts;
+    PointTable Tc;
     __shared__ float red[32];
     __shared__ int s_timed_out;
-    const PointTable* T = nullptr;
-    if (MODE == MODE_NEAREST) { load_points(Ts, p.pts, p.k); T = &Ts; }
+    const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -2280,13 +2407,16 @@ int launch_bucketed(KParams& p, hipStream_t st) {
                          (MODE != MODE_NEAREST || p.idx == nullptr || p.idx_bytes != 8 || (((uintptr_t)p.idx) & 15) == 0) &&
                          (MODE != MODE_QDQ || p.lev8 == nullptr || (((uintptr_t)p.lev8) & 3) == 0);
     const int64_t nfull = p.n / p.row;                 // leading full buckets
+    const size_t tb = MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0;      // dynamic LDS of every launch: the point table
+    // k_bucket_chunk_any stages level / point indices that fit a byte in LDS (the same expression as in the kernel)
+    const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 256);
 #define QD_VEC(LPB, V, U)                                                                       \
     {                                                                                           \
         p.nvec = nfull;                                                                         \
         constexpr int64_t bpw = (64 / LPB) * U;                                                 \
         const int64_t tiles = (nfull + bpw - 1) / bpw;                                          \
         const int blocks = blocks_for(tiles, 4) + 1; /* +1: the block that owns the tail */     \
-        hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V, U>), dim3(blocks), dim3(256), 0, st, p); \
+        hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V, U>), dim3(blocks), dim3(256), tb, st, p); \
         return check_launch();                                                                  \
     }
     if (aligned && p.nb > 1) {
@@ -2323,7 +2453,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     {                                                                                                      \
         const int64_t nbk = V > 16 ? nbk_whole : nbk_all;                                                  \
         const int blocks = blocks_for(nbk > 0 ? nbk : 1, 4 / G);                                           \
-        hipLaunchKernelGGL((k_bucket_wave_any<MODE, V, G>), dim3(blocks), dim3(256), 0, st, p, nbk, amask); \
+        hipLaunchKernelGGL((k_bucket_wave_any<MODE, V, G>), dim3(blocks), dim3(256), tb, st, p, nbk, amask); \
         return check_launch();                                                                             \
     }
             // one wave per bucket up to 8 rounds (2048 elements), then two (up to 4096) and four waves per bucket
@@ -2386,7 +2516,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         if (nchunks > 0) {
             const size_t lds = (size_t)2 * (kChunkV * 64 + 256 + 128) * sizeof(float2);   // two waves per block: pairs, (alpha, beta), 1/alpha
             const int blocks = blocks_for(nchunks, 2) + 1;                             // +1: the block that owns the tail
-            hipLaunchKernelGGL((k_bucket_chunk<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks);
+            hipLaunchKernelGGL((k_bucket_chunk<MODE, kChunkV>), dim3(blocks), dim3(128), lds + tb, st, p, m, nchunks);
             return check_launch();
         }
     }
@@ -2403,28 +2533,29 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         if (m < 64) { int p2 = 4; while (p2 * 2 <= m) p2 *= 2; if (m < 48 || p2 == m) m = p2; }
         const int64_t nchunks = nfull / m;
         if (nchunks > 0) {
-            const size_t lds = (size_t)2 * (kChunkV * 128) * sizeof(float2);              // two waves: the staged chunk
+            // two waves: the staged chunk, + a byte per element when level / point indices (<= 255) are asked for
+            const size_t lds = (size_t)2 * (kChunkV * 256 + (stage8 ? kChunkV * 64 : 0)) * sizeof(float);
             const int blocks = blocks_for(nchunks, 2) + 1;
-            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds, st, p, m, nchunks, lead);
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds + tb, st, p, m, nchunks, lead);
             return check_launch();
         }
     }
     if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row > 512 && p.row <= 1024) {     // four buckets per chunk, 16 float4 per lane
         const int64_t nchunks = nfull / 4;
         if (nchunks > 0) {
-            const size_t lds = (size_t)2 * (16 * 128) * sizeof(float2);
+            const size_t lds = (size_t)2 * (16 * 256 + (stage8 ? 16 * 64 : 0)) * sizeof(float);
             const int blocks = blocks_for(nchunks, 2) + 1;
-            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds, st, p, 4, nchunks,
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds + tb, st, p, 4, nchunks,
                                p.row * 4 + 28 <= 16 * 256 ? 1 : 0);
             return check_launch();
         }
     }
     if (p.row <= 256) {                                  // 16 buckets per block, a DPP row each
-        hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16)), dim3(256), tb, st, p);
     } else if (p.row <= 16384) {                         // 4 buckets per block, one wave each
-        hipLaunchKernelGGL((k_bucket_groups<MODE, 64>), dim3(blocks_for(p.nb, 4)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((k_bucket_groups<MODE, 64>), dim3(blocks_for(p.nb, 4)), dim3(256), tb, st, p);
     } else {
-        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(blocks_for(p.nb, 1)), dim3(1024), 0, st, p);
+        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(blocks_for(p.nb, 1)), dim3(1024), tb, st, p);
     }
     return check_launch();
 }
@@ -2442,7 +2573,7 @@ int fused_capacity() {                                         // blocks of k_si
         int per_cu = 0;
         hipFuncAttributes fa;
         const void* fn = (const void*)k_single_fused<MODE, V, W>;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, MODE == MODE_NEAREST ? point_table_bytes(kMaxPoints) : 0) != hipSuccess ||
             hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.localSizeBytes != 0 /* spills: not worth it */)
             per_cu = 0;
         (void)hipGetLastError();
@@ -2489,7 +2620,8 @@ int launch_single_fused(KParams& p, hipStream_t st) {
             } while (tag_min == 0u || tag_max == 0u);                                                      \
             const int slot = (int)(epoch % kFusedSlots);                                                   \
             p.nvec = 0;                                                                                    \
-            hipLaunchKernelGGL((k_single_fused<MODE, V, W>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, p, \
+            hipLaunchKernelGGL((k_single_fused<MODE, V, W>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), \
+                               MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0, st, p, \
                                slot, tag_min, tag_max, fmode >= 2 ? fmode - 1 : 0);          \
             return check_launch();                                                                         \
         }                                                                                                  \
@@ -2505,7 +2637,7 @@ int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int64_t kSmall = 16384;
     if (p.n <= kSmall) {                               // one block does both passes, one launch
         p.nvec = 0;
-        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(1), dim3(1024), 0, st, p);
+        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(1), dim3(1024), MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0, st, p);
         return check_launch();
     }
     Workspace w;
@@ -2532,7 +2664,8 @@ int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
         }
     }
     const int blocks = blocks_for(p.n, 256 * 4 * 4);
-    hipLaunchKernelGGL((k_single_apply<MODE>), dim3(blocks), dim3(256), 0, st, p, ab, w.minmax_part, nparts);
+    hipLaunchKernelGGL((k_single_apply<MODE>), dim3(blocks), dim3(256), MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0, st, p, ab,
+                       w.minmax_part, nparts);
     return check_launch();
 }
 

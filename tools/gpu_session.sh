@@ -11,6 +11,7 @@
 #   ragged     tools/ragged_probe.py
 #   api        tools/profile_api_overhead.py
 #   soak       property tests with QD_SOAK=10
+#   side       tools/side_output_probe.py (calls with index / level side outputs at every bucket-size family; SIDE_ARGS)
 #   spread     tools/distill_spread_probe.py: repetition-to-repetition spread of the configs[1] step, with a kernel trace
 #   stack      ROCm / driver / torch versions of the box
 set +e
@@ -40,6 +41,7 @@ for step in "$@"; do
     ragged)  timeout 600 python tools/ragged_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/ragged.txt; cat gpurun_out/ragged.txt ;;
     api)     timeout 600 python tools/profile_api_overhead.py 2>&1 | grep -v amdgpu.ids > gpurun_out/api_overhead.txt; head -8 gpurun_out/api_overhead.txt ;;
     soak)    QD_SOAK=10 timeout 1500 python -m pytest tests/test_hip_property.py -x -q -m gpu > gpurun_out/property_soak.log 2>&1; tail -2 gpurun_out/property_soak.log ;;
+    side)    timeout 900 python tools/side_output_probe.py $SIDE_ARGS 2>&1 | grep -v amdgpu.ids > gpurun_out/side_output.txt; cat gpurun_out/side_output.txt ;;
     spread)  timeout 600 python tools/distill_spread_probe.py --sleep 0.5 2>&1 | grep -v amdgpu.ids > gpurun_out/distill_spread.txt; head -20 gpurun_out/distill_spread.txt
              rm -rf gpurun_out/spread_trace
              (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/spread_trace -o spread -- python $R/tools/distill_spread_probe.py --marks --reps 8 > $R/gpurun_out/distill_spread_traced.txt 2> $R/gpurun_out/spread.err); echo "trace rc=$?"
