@@ -87,11 +87,13 @@ __host__ __device__ constexpr size_t point_table_bytes(int k) {
                             : (size_t)2 * kMaxPoints * sizeof(float) + (size_t)2 * (kCells + 4) * sizeof(int);
 }
 
-// What the kernels pass around: a handle on the LDS table.  (Tried in round 3 and dropped: for k <= 8 the points and
-// midpoints themselves in wave-uniform registers, the assignment as k - 1 compares and selects without any LDS access.
-// 23 more live scalar values pushed the kernels' SGPR use over the limit (88-179 SGPR spills into VGPR lanes) and the
-// pre-processed forward got SLOWER at every bucket size: k = 4, bucket 256 / 100 / 1000: 107 / 192 / 130 us against
-// 93 / 114 / 97 us with the joint LDS search of count_before4 -- profiles/r03_side_outputs.txt.)
+// What the kernels pass around: a handle on the LDS table.  (Tried in round 3 and dropped: for small point sets the points
+// and midpoints themselves in registers, the assignment as k - 1 compares and selects without any LDS access.  With k <= 8
+// and the values forced into scalar registers, 23 more live SGPRs put the kernels 88-179 SGPR spills over the limit and the
+// pre-processed forward got slower at every bucket size -- k = 4, bucket 256 / 100 / 1000: 107 / 192 / 130 us against
+// 93 / 114 / 97 us with the joint LDS search of count_before4.  With k <= 4 in vector registers (+26 VGPRs in the chunk
+// kernel) it tied or lost on the per-step call (bucket 100: 119 us against 105 us) and gained 5-10 % on the one-off
+// nonUniformQuantization call only.  profiles/r03_side_outputs.txt.)
 struct PointTable {
     const PointStore* s;
 };

@@ -36,9 +36,9 @@ record('K1 uniform 4-bit bucket 100 (chunk kernel)', 'k_bucket_chunk<0, 8>', 8 *
        lambda i: keep.append(quantization.uniformQuantization(xs[i + 3], 16, bucket_size=100)[0]))
 record('K1 uniform 4-bit bucket 33 (chunk_any kernel)', 'k_bucket_chunk_any<0, 8>', 8 * N,
        lambda i: keep.append(quantization.uniformQuantization(xs[i], 16, bucket_size=33)[0]))
-record('K1 uniform 4-bit bucket 1000 (one wave per bucket, any size)', 'k_bucket_wave_any<5>', 8 * N,
+record('K1 uniform 4-bit bucket 1000 (one wave per bucket, any size)', 'k_bucket_wave_any<0, 5, 1>', 8 * N,
        lambda i: keep.append(quantization.uniformQuantization(xs[i + 3], 16, bucket_size=1000)[0]))
-record('K1 uniform 4-bit bucket 513 (one wave per bucket, any size)', 'k_bucket_wave_any<3>', 8 * N,
+record('K1 uniform 4-bit bucket 513 (one wave per bucket, any size)', 'k_bucket_wave_any<0, 3, 1>', 8 * N,
        lambda i: keep.append(quantization.uniformQuantization(xs[i], 16, bucket_size=513)[0]))
 lev = [torch.randint(0, 16, (N,), dtype=torch.uint8, device=dev) for _ in range(3)]
 record('HST level histogram k=16 (LDS integer atomics + fold)', 'k_hist_atomic<2>', N, lambda i: keep.append(codec.histogram_u8(lev[i], 16)))
@@ -67,6 +67,22 @@ record('PK pack 4-bit', 'k_pack_vec<16, 4, 4>', int(4.5 * N), lambda i: keep.app
 pk = codec.pack_uniform(xs[0], 16, 256)
 counts['k_pack_vec<16, 4, 4>'] += 1
 record('UPK unpack 4-bit', 'k_unpack<4>', int(4.5 * N), lambda i: keep.append(pk.unpack()))
+# round 3: the calls with a side output at the bucket sizes of the chunk kernels
+for b, kern4, kern5 in ((100, 'k_bucket_chunk<2, 8>', 'k_bucket_chunk<2, 8>'), (33, 'k_bucket_chunk_any<2, 8>', 'k_bucket_chunk_any<2, 8>'),
+                        (250, 'k_bucket_chunk_any<2, 8>', 'k_bucket_chunk_any<2, 8>')):
+    record('K4 nonUniform k=4 int64 idx bucket %d' % b, kern4, 16 * N,
+           lambda i, b=b: keep.append(quantization.nonUniformQuantization(xs[i], pts, bucket_size=b)[:2]))
+    fb = [quantization.nonUniformQuantization_variable(bucket_size=b, pre_process_tensors=True, tensor=xs[i + 3]) for i in range(3)]
+    record('K5 pre-processed forward k=4 u8 idx bucket %d' % b, kern5, 9 * N, lambda i, fb=fb: keep.append(fb[i].forward(None, pts)))
+    del fb
+lib = _lib.load()
+ws = _lib.workspace(dev)
+levo = [torch.empty(N, dtype=torch.uint8, device=dev) for _ in range(3)]
+qo = [torch.empty(N, device=dev) for _ in range(3)]
+for b, kern in ((33, 'k_bucket_chunk_any<0, 8>'), (256, 'k_bucket_vec<0, 16, 4, 1>')):
+    record('L8 quantize + uint8 levels bucket %d' % b, kern, 9 * N,
+           lambda i, b=b: lib.qd_uniform_f32(xs[i].data_ptr(), qo[i].data_ptr(), N, b, 16, None, None, levo[i].data_ptr(), None, 0, 0.0, 0, 0,
+                                             ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
 torch.cuda.synchronize()
 out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
 os.makedirs(out_dir, exist_ok=True)
