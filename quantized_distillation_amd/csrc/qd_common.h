@@ -324,8 +324,8 @@ __device__ __forceinline__ float qdq_stochastic_tab(float v, float a, float b, f
 
 // ---- sorted-array searches over LDS (uniform trip count, branch-free) ----
 // count of a[j] <  u (lower bound) when UPPER == false; count of a[j] <= u when UPPER == true
-template <bool UPPER>
-__device__ __forceinline__ int count_before(const float* a, int n, float u) {
+template <bool UPPER, typename P>      // P: pointer to float in any address space (LDS tables pass address_space(3) pointers)
+__device__ __forceinline__ int count_before(P a, int n, float u) {
     int lo = 0;
     while (n > 1) {
         const int half = n >> 1;
@@ -346,8 +346,8 @@ __device__ __forceinline__ int count_before(const float* a, int n, float u) {
 // independent -- one LDS round trip per step and float4 instead of four dependent chains one after the other.  (A kernel
 // that holds several float4s per lane at two or three waves per SIMD cannot hide those chains behind other waves: the
 // pre-processed forward at bucket 100 ran at 145 us against 94 us for the same kernel without the point search.)
-template <bool UPPER>
-__device__ __forceinline__ void count_before4(const float* a, int n, const float (&u)[4], int (&lo)[4]) {
+template <bool UPPER, typename P>
+__device__ __forceinline__ void count_before4(P a, int n, const float (&u)[4], int (&lo)[4]) {
     lo[0] = 0; lo[1] = 0; lo[2] = 0; lo[3] = 0;
     while (n > 1) {
         const int half = n >> 1;

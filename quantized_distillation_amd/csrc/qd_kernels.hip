@@ -74,11 +74,15 @@ constexpr int kCells = 256;             // uniform grid over [0,1] that narrows 
 // sized by the number of points: 256 bytes up to 32 points -- every configuration of the reference's scripts -- instead of
 // a static 10.3 KB for the 1024 points the ABI allows.  (The static table left the chunk kernels 6 / 5 blocks per CU, bound
 // by LDS; the point search is a chain of dependent LDS reads, so resident waves are what hides it.)
+// (pointers in the LDS address space: 32-bit addresses and ds_read straight away, instead of 64-bit generic pointers that
+// the compiler first has to prove to be LDS -- the k = 256 search is VALU- and bank-conflict-bound, every instruction counts)
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) int lds_i32;
 struct PointStore {
-    float* pts;                         // [cap]
-    float* mid;                         // [cap]
-    int* start;                         // [kCells + 4], k > 32 only: start[c] = #{ j : cell(mid_j) < c }, c = 0..kCells
-    int* startp;                        // same for the points themselves (distance rule)
+    lds_f32* pts;                       // [cap]
+    lds_f32* mid;                       // [cap]
+    lds_i32* start;                     // [kCells + 4], k > 32 only: start[c] = #{ j : cell(mid_j) < c }, c = 0..kCells
+    lds_i32* startp;                    // same for the points themselves (distance rule)
 };
 extern __shared__ __attribute__((aligned(16))) unsigned char qd_dyn_lds[];     // every kernel's dynamic LDS starts here
 constexpr int kSmallTable = 32;
@@ -108,9 +112,9 @@ __device__ __forceinline__ int cell_of(float u) {
 
 __device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const float* pts, int k) {
     const int cap = k <= kSmallTable ? kSmallTable : kMaxPoints;
-    T.pts = (float*)qd_dyn_lds;
+    T.pts = (lds_f32*)qd_dyn_lds;
     T.mid = T.pts + cap;
-    T.start = (int*)(T.mid + cap);
+    T.start = (lds_i32*)(T.mid + cap);
     T.startp = T.start + (kCells + 4);
     for (int j = threadIdx.x; j < k; j += blockDim.x) T.pts[j] = pts[j];
     __syncthreads();
@@ -204,6 +208,11 @@ __device__ __forceinline__ float transform(const KParams& p, const PointTable* T
 // (count_before4); above that each element narrows its own search to its grid cell as assign_point does.
 __device__ __forceinline__ void assign_point4(const PointStore& T, int k, int mode, const float (&u)[4], int (&i)[4]) {
     if (k > 32) {
+        // Many points: each element narrows its own search to its grid cell (assign_point).  Advancing the four narrowed
+        // searches together was tried and dropped: at k = 256 this kernel is bound by LDS bank conflicts and VALU issue, not
+        // by latency (random reads of a 256-entry table: SQ_LDS_BANK_CONFLICT 18.7 M of 34.8 M LDS-active cycles per 64 Mi-
+        // element launch, 61.6 M VALU wave-instructions against 24.9 M at k = 4), and the always-issued reads of a joint
+        // loop made both worse (28.1 M conflict cycles, 85.3 M VALU: 134 us against 115 us; profiles/r03_sq_counters.txt).
 #pragma unroll
         for (int c = 0; c < 4; ++c) i[c] = assign_point(T, k, mode, u[c]);
         return;

@@ -11,6 +11,7 @@
 #   ragged     tools/ragged_probe.py
 #   api        tools/profile_api_overhead.py
 #   soak       property tests with QD_SOAK=10
+#   sq         SQ counters (VALU / LDS instructions, LDS bank conflicts) of the nearest-point calls, before / after
 #   side       tools/side_output_probe.py (calls with index / level side outputs at every bucket-size family; SIDE_ARGS)
 #   spread     tools/distill_spread_probe.py: repetition-to-repetition spread of the configs[1] step, with a kernel trace
 #   stack      ROCm / driver / torch versions of the box
@@ -41,6 +42,15 @@ for step in "$@"; do
     ragged)  timeout 600 python tools/ragged_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/ragged.txt; cat gpurun_out/ragged.txt ;;
     api)     timeout 600 python tools/profile_api_overhead.py 2>&1 | grep -v amdgpu.ids > gpurun_out/api_overhead.txt; head -8 gpurun_out/api_overhead.txt ;;
     soak)    QD_SOAK=10 timeout 1500 python -m pytest tests/test_hip_property.py -x -q -m gpu > gpurun_out/property_soak.log 2>&1; tail -2 gpurun_out/property_soak.log ;;
+    sq)      # SQ counters of the nearest-point calls, current library and (when present) build/libqd_hip_prev.so; dispatch order
+             # inside tools/sq_probe_r3.py: K5 bucket 256 k = 256 / 16 / 4, bucket 100 k = 4, bucket 33 k = 4, bucket 100 k = 256
+             for tag in cur prev; do
+               [ $tag = prev ] && { [ -f build/libqd_hip_prev.so ] || continue; export QD_LIB=$R/build/libqd_hip_prev.so; }
+               rm -rf gpurun_out/sq_$tag
+               (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $R/gpurun_out/sq_$tag -o sq -- python $R/tools/sq_probe_r3.py > /dev/null 2> $R/gpurun_out/sq_$tag.err); echo "sq $tag rc=$?"
+               unset QD_LIB
+             done
+             python tools/sq_summarize_r3.py > gpurun_out/sq_counters.txt 2>&1; cat gpurun_out/sq_counters.txt ;;
     side)    timeout 900 python tools/side_output_probe.py $SIDE_ARGS 2>&1 | grep -v amdgpu.ids > gpurun_out/side_output.txt; cat gpurun_out/side_output.txt ;;
     spread)  timeout 600 python tools/distill_spread_probe.py --sleep 0.5 2>&1 | grep -v amdgpu.ids > gpurun_out/distill_spread.txt; head -20 gpurun_out/distill_spread.txt
              rm -rf gpurun_out/spread_trace
