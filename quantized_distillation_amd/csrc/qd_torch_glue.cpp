@@ -333,8 +333,8 @@ PyObject* glue_uniform_common(PyObject*, PyObject* const* args, Py_ssize_t nargs
 //   One qd_nearest_point_f32 launch.
 PyObject* glue_nearest(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     HANDLE_TH_ERRORS
-    if (nargs != 12) {
-        PyErr_SetString(PyExc_TypeError, "nearest() takes 12 positional arguments");
+    if (nargs != 12 && nargs != 13) {
+        PyErr_SetString(PyExc_TypeError, "nearest() takes 12 or 13 positional arguments");
         return nullptr;
     }
     const at::Tensor& x = tensor_arg(args[0], "tensor");
@@ -349,6 +349,7 @@ PyObject* glue_nearest(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     const int clamp = PyObject_IsTrue(args[9]);
     const double max_element = PyFloat_AsDouble(args[10]);
     const long idx_bytes = PyLong_AsLong(args[11]);
+    const int in_place = nargs == 13 ? PyObject_IsTrue(args[12]) : 0;      // q written over x (modify_in_place=True): no copy pass
     if (PyErr_Occurred()) return nullptr;
     require_device_f32(x, "tensor");
     require_device_f32(points, "points");
@@ -360,7 +361,7 @@ PyObject* glue_nearest(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     c10::hip::OptionalHIPGuard guard;
     if (dev.index() != c10::hip::current_device()) guard.set_index(dev.index());
     void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-    at::Tensor q = empty_f32({static_cast<int64_t>(n)}, dev);
+    at::Tensor q = in_place ? x.view({x.numel()}).narrow(0, 0, static_cast<int64_t>(n)) : empty_f32({static_cast<int64_t>(n)}, dev);
     at::Tensor idx = empty_of({static_cast<int64_t>(n)}, idx_bytes == 8 ? at::kLong : at::kByte, dev);
     if (n > 0) {
         void* ws = nullptr;

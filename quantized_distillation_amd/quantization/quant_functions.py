@@ -497,10 +497,11 @@ def _points_on(points, device):
     return points
 
 
-def _nearest(x, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mean_buf, clamp, me, idx_bytes):
-    """(q [n], idx [n]) -- one K4/K5 launch through the native binding (allocation + stream + launch)."""
+def _nearest(x, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mean_buf, clamp, me, idx_bytes, in_place=False):
+    """(q [n], idx [n]) -- one K4/K5 launch through the native binding (allocation + stream + launch).  in_place: q is
+    written over x (every kernel of the family loads a bucket before it stores it)."""
     return _lib.glue().nearest(x, prescaled, points, assign_mode, n, bucket_size or 0, alpha, beta, mean_buf,
-                               clamp, me, idx_bytes)
+                               clamp, me, idx_bytes, in_place)
 
 
 def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
@@ -541,10 +542,7 @@ def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
         sf._alloc_alpha_beta(nb, tensor.device)
         clamp, me = sf._clamp_args()
         q, idx = _nearest(tensor, False, points, 0, n, bucket_size, sf.alpha, sf.beta, sf._mean_buf,
-                          clamp, me, 8)
-        if modify_in_place:
-            tensor.view(-1).copy_(q)
-            q = tensor
+                          clamp, me, 8, in_place=bool(modify_in_place))          # in place: the kernel writes over the input
         return q.view(sf.original_tensor_size), idx.view(sf.original_tensor_size), sf
 
     sf = scaling_function

@@ -140,6 +140,32 @@ def test_modify_in_place_and_views():
     assert q.numel() == 0
 
 
+@pytest.mark.parametrize('bucket', [256, 1024, 100, 33, 250, 513, 1000, 5000, None])
+def test_nonuniform_modify_in_place_on_every_kernel_family(bucket):
+    """nonUniformQuantization(modify_in_place=True): the kernel writes over its input (round 2 quantized out of place and
+    copied back: +8 B/element) -- vector, chunk, chunk_any, one-wave-per-bucket and single-bucket kernels, ragged tails,
+    a tensor small enough for the one-launch single-bucket kernel (which in-place calls must not take): values and int64
+    indices bit-identical to the out-of-place call and to the C oracle, arg indices taken before the overwrite.
+    ref: quant_functions.py:243-290."""
+    rng = np.random.RandomState(11 + (bucket or 0))
+    pts = np.array([0.0, 0.25, 0.6, 1.0], np.float32)
+    for n in (70001, 300000 + 3, 1 << 20):
+        x = rng.randn(n).astype(np.float32)
+        want = oc.nonuniform_quantize(x, pts, bucket)
+        xd = dev(x)
+        q0, i0, sf0 = quantization.nonUniformQuantization(xd, dev(pts), bucket_size=bucket)
+        assert np.array_equal(host(xd), x), 'out of place: the input is untouched'
+        imin0, imax0 = sf0.idx_min_rows.clone(), sf0.idx_max_rows.clone()          # (lazy: read before xd is overwritten)
+        q1, i1, sf1 = quantization.nonUniformQuantization(xd, dev(pts), bucket_size=bucket, modify_in_place=True)
+        assert q1.data_ptr() == xd.data_ptr()
+        assert np.array_equal(host(q1), want['q']) and np.array_equal(host(i1), want['idx']), (bucket, n)
+        assert torch.equal(q0, q1) and torch.equal(i0, i1)
+        assert torch.equal(sf0.alpha, sf1.alpha) and torch.equal(sf0.beta, sf1.beta)
+        assert torch.equal(imin0, sf1.idx_min_rows) and torch.equal(imax0, sf1.idx_max_rows)
+    with pytest.raises(ValueError):
+        quantization.nonUniformQuantization(dev(rng.randn(64, 48).astype(np.float32)).t(), dev(pts), bucket_size=bucket, modify_in_place=True)
+
+
 @pytest.mark.parametrize('bucket', [64, 128, 256, 512, 1024, 2048, 4096, 100, 3, None])
 def test_uniform_random_sweep_vs_c_oracle(bucket):
     rng = np.random.RandomState(11)
