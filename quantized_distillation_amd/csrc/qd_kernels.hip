@@ -112,9 +112,12 @@ __device__ __forceinline__ int cell_of(float u) {
 
 __device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const float* pts, int k) {
     const int cap = k <= kSmallTable ? kSmallTable : kMaxPoints;
-    T.pts = (lds_f32*)qd_dyn_lds;
-    T.mid = T.pts + cap;
-    T.start = (lds_i32*)(T.mid + cap);
+    // midpoints FIRST and the cell tables at a constant distance: the searches of the per-step call (midpoint rule) then
+    // address LDS with compile-time offsets again, whatever the table size; only the points sit at a k-dependent offset
+    // (with both arrays behind a run-time offset the k = 256 search, which is VALU-bound, issued 5 % more instructions)
+    T.mid = (lds_f32*)qd_dyn_lds;
+    T.pts = T.mid + cap;
+    T.start = (lds_i32*)(T.mid + 2 * kMaxPoints);            // (k > 32 only, where cap == kMaxPoints)
     T.startp = T.start + (kCells + 4);
     for (int j = threadIdx.x; j < k; j += blockDim.x) T.pts[j] = pts[j];
     __syncthreads();
@@ -203,20 +206,14 @@ __device__ __forceinline__ float transform(const KParams& p, const PointTable* T
     }
 }
 
-// nearest points of the four elements of a float4.  Up to 32 points (every configuration of the reference's scripts:
-// 2^bits points, bits <= 4 in the differentiable-quantization runs): the four searches advance together
-// (count_before4); above that each element narrows its own search to its grid cell as assign_point does.
+// nearest points of the four elements of a float4, up to 32 points (every configuration of the reference's scripts:
+// 2^bits points, bits <= 4 in the differentiable-quantization runs): the four searches advance together (count_before4).
+// Above 32 points transform_x4 keeps the element-by-element form of assign_point: there the kernel is bound by VALU issue
+// and LDS bank conflicts, not by latency (at k = 256: 64 M VALU wave-instructions per 64 Mi-element launch ~ 105 us of
+// issue time, half of the 35.7 M LDS-active cycles lost to conflicts of random reads in 256-entry tables), and both a
+// joint narrowed search with always-issued reads (134 us against 115 us) and merely routing the four per-element searches
+// through this function (125 us) measured slower.  profiles/r03_sq_counters.txt.
 __device__ __forceinline__ void assign_point4(const PointStore& T, int k, int mode, const float (&u)[4], int (&i)[4]) {
-    if (k > 32) {
-        // Many points: each element narrows its own search to its grid cell (assign_point).  Advancing the four narrowed
-        // searches together was tried and dropped: at k = 256 this kernel is bound by LDS bank conflicts and VALU issue, not
-        // by latency (random reads of a 256-entry table: SQ_LDS_BANK_CONFLICT 18.7 M of 34.8 M LDS-active cycles per 64 Mi-
-        // element launch, 61.6 M VALU wave-instructions against 24.9 M at k = 4), and the always-issued reads of a joint
-        // loop made both worse (28.1 M conflict cycles, 85.3 M VALU: 134 us against 115 us; profiles/r03_sq_counters.txt).
-#pragma unroll
-        for (int c = 0; c < 4; ++c) i[c] = assign_point(T, k, mode, u[c]);
-        return;
-    }
     if (mode == QD_ASSIGN_MIDPOINT) {
         count_before4<true>(T.mid, k - 1, u, i);
         return;
@@ -241,7 +238,7 @@ template <int MODE, bool FAST = false>
 __device__ __forceinline__ void transform_x4(const KParams& p, const PointTable* T, const float (&v)[4], float a, float b,
                                              float mean, const float (&rnd)[4], float (&side)[4], float (&out)[4],
                                              float y = 0.0f) {
-    if (MODE == MODE_NEAREST) {
+    if (MODE == MODE_NEAREST && p.k <= 32) {
         float u[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -811,8 +808,10 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
     // Side outputs (level / point indices up to 255) are staged as ONE BYTE per element behind the values -- a quarter more
     // LDS, only when such an output is asked for -- and leave with the values: four per lane, coalesced.  Stored from the
     // transform loop they would leave element by element in LDS order (lanes a bucket apart): 216 us instead of 95 us for
-    // quantize + levels at bucket 33, 405 us for int64 point indices (profiles/r03_side_outputs.txt).
-    const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 256);
+    // quantize + levels at bucket 33, 405 us for int64 point indices (profiles/r03_side_outputs.txt).  (Up to 32 points: with
+    // the 10.3 KB table of a larger point set the extra bytes cost a resident block, which measured slower than the scattered
+    // stores: k = 256 at bucket 33: 316 us against 281 us.)
+    const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 32);
     const int wave_floats = VMAX * 256 + (stage8 ? VMAX * 64 : 0);
     float* vals = (float*)chunk_lds + w * wave_floats;
     uint8_t* sidev = (uint8_t*)(vals + VMAX * 256);
@@ -2420,7 +2419,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
     const int64_t nfull = p.n / p.row;                 // leading full buckets
     const size_t tb = MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0;      // dynamic LDS of every launch: the point table
     // k_bucket_chunk_any stages level / point indices that fit a byte in LDS (the same expression as in the kernel)
-    const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 256);
+    const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 32);
 #define QD_VEC(LPB, V, U)                                                                       \
     {                                                                                           \
         p.nvec = nfull;                                                                         \
