@@ -80,3 +80,34 @@ def test_staged_reference_training_loop_runs_on_cpu_with_the_reference_quantizer
         _, info = loop.train_model(model, batches, batches[:1], epochs_to_train=1, print_every=1, quantizeWeights=True,
                                    numBits=4, bucket_size=256)
     assert info['errorFlag'] is False and info['numEpochsTrained'] == 1 and len(info['lossSaved']) == 1
+
+
+@pytest.mark.skipif(not (ref_stage.patched_is_staged() or os.path.exists(ref_stage.REF_ROOT)), reason='patched reference not staged')
+def test_staged_patched_reference_reproduces_the_ste_golden_vectors(golden_ste):
+    """oracle/_ref/patched: the reference with the two shape fixes of SURVEY 8c applied to its source text in memory before
+    compiling (ref_stage.stage_patched) -- what the GPU tests of the 'complicated' style compare with.  It IS the patched
+    reference tests/golden/gen_golden.py ran: its backward reproduces every golden STE vector bit for bit; everything else
+    in it is the unpatched reference (same forward, same golden vectors); and the UNPATCHED package still raises for more
+    than one bucket, which is why the patched one exists (quant_functions.py:369-371,398-400)."""
+    import sys
+    import quantization as product
+    patched = ref_stage.load_patched()
+    plain = ref_stage.load()
+    assert patched is not None and patched is not plain and patched is not product
+    assert sys.modules['quantization'] is product
+    assert os.path.abspath(patched.__file__).startswith(ref_stage.PATCHED_DIR)
+    assert not os.path.exists(os.path.join(ref_stage.PATCHED_PKG, 'quant_functions.py')), 'bytecode only'
+    G = golden_ste
+    for i, c in enumerate(G.meta):
+        x, g = torch.from_numpy(G.arr('s', i, 'x').copy()), torch.from_numpy(G.arr('s', i, 'g').copy())
+        fn = patched.uniformQuantization_variable(c['s'], bucket_size=c['bucket'])
+        q = fn.forward(x)
+        assert np.array_equal(q.numpy(), G.arr('s', i, 'q')), (i, c)
+        out = fn.backward(g.clone())
+        assert fn.saved_for_backward is None
+        assert np.array_equal(out.numpy(), G.arr('s', i, 'gout')), (i, c)
+    x = torch.randn(1000)
+    fn = plain.uniformQuantization_variable(16, bucket_size=256)
+    fn.forward(x)
+    with pytest.raises(RuntimeError):
+        fn.backward(torch.randn(1000))
