@@ -20,8 +20,8 @@ def hipcc():
     return exe
 
 
-SOURCES = ['qd_kernels.hip', 'qd_codec.hip', 'qd_multi_dq.hip', 'qd_abs.hip', 'qd_multi_global.hip', 'qd_select.hip',
-           'qd_selftest.hip']
+SOURCES = ['qd_kernels.hip', 'qd_nearest.hip', 'qd_reductions.hip', 'qd_scale.hip', 'qd_codec.hip', 'qd_multi_dq.hip', 'qd_abs.hip', 'qd_multi_global.hip',
+           'qd_select.hip', 'qd_selftest.hip']
 OBJ_DIR = os.path.join(os.path.dirname(_lib.INCLUDE), 'build', 'obj')              # git-ignored; objects are rebuilt from source when stale
 
 
@@ -35,7 +35,8 @@ def build_extension(force=False, verbose=False, save_temps_dir=None):
     scratch / LDS metadata from it)."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(_lib.CSRC, f) for f in SOURCES]
-    hdrs = [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h'), os.path.abspath(__file__)]
+    hdrs = [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.CSRC, 'qd_transform.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h'),
+            os.path.abspath(__file__)]
     out = _lib.LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs = [os.path.join(OBJ_DIR, os.path.splitext(f)[0] + '.o') for f in SOURCES]
