@@ -19,6 +19,7 @@ int qd_nearest_point_f32(const float* x, int prescaled, const float* points, int
     p.me = clamp ? max_element : INFINITY;
     p.idx = idx; p.idx_bytes = idx_bytes; p.pts = points; p.k = k; p.assign_mode = assign_mode;
     p.prescaled = prescaled ? 1 : 0;
+    p.fine = (k > 32 && assign_mode == QD_ASSIGN_MIDPOINT) ? 1 : 0;      // the fine cell table of qd_transform.h
     return run_transform<MODE_NEAREST>(p, bucket, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

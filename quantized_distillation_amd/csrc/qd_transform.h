@@ -68,6 +68,7 @@ struct KParams {
     int k;
     int assign_mode;
     int prescaled;       // NEAREST: x is already u, alpha/beta are inputs
+    int fine;            // NEAREST, midpoint rule, k > 32: the kernel builds and uses the fine cell table (see PointStore)
     int stochastic;
     uint64_t seed;
     int64_t nvec;        // number of leading full buckets handled by the vector path
@@ -84,17 +85,41 @@ constexpr int kCells = 256;             // uniform grid over [0,1] that narrows 
 // the compiler first has to prove to be LDS -- the k = 256 search is VALU- and bank-conflict-bound, every instruction counts)
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) int lds_i32;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));      // (a native vector: HIP's uint2 class has no LDS-qualified operators)
+typedef __attribute__((address_space(3))) u32x2 lds_u2;
 struct PointStore {
     lds_f32* pts;                       // [cap]
     lds_f32* mid;                       // [cap]
     lds_i32* start;                     // [kCells + 4], k > 32 only: start[c] = #{ j : cell(mid_j) < c }, c = 0..kCells
     lds_i32* startp;                    // same for the points themselves (distance rule)
+    lds_u2* cell;                       // [kFineCells], `fine` only: {start | count << 16, first midpoint of the cell}
 };
 extern __shared__ __attribute__((aligned(16))) unsigned char qd_dyn_lds[];     // every kernel's dynamic LDS starts here
 constexpr int kSmallTable = 32;
-__host__ __device__ constexpr size_t point_table_bytes(int k) {
+// Many points, midpoint rule (the per-step call): a FINE grid of 2048 cells over [0, 1] whose entry answers an element by
+// itself when its cell holds at most one midpoint -- index = start + (first midpoint <= u) -- with ONE 8-byte LDS read, no
+// loop; only cells with two or more midpoints fall back to the binary search inside the cell.  With k = 256 points spread
+// like uniform samples 0.7 % of the elements need the fallback (a wave executes it for an element slot in which any of its
+// 64 lanes does: about once per three float4 instead of for every element).  Why: at k = 256 the kernel is bound by VALU
+// issue and LDS bank conflicts, not by latency -- 61 M VALU wave-instructions per 64 Mi-element launch (25 M at k = 4), half
+// of its 35.7 M LDS-active cycles lost to conflicts of five to six random table reads per element
+// (profiles/r03_sq_counters.txt).  Points crowded into few cells (percentile-initialised, bell-shaped weights) keep taking the
+// fallback: never slower than the narrowed search it replaces, only no faster.  16 KB more LDS, so only the kernels without
+// LDS staging of their own use it (`fine` is cleared for the chunk kernels), on a capped grid (kFineBlocksPerCu) so that
+// the table is built a few thousand times, not once per 16 KB of data.
+constexpr int kFineCells = 2048;
+// Grid cap of the kernels that build the fine table, in blocks per CU (6 are resident next to 26.6 KB of LDS).  Measured, K5
+// k = 256 at bucket 256 / 1000, 64 Mi elements (round 2's narrowed search: 117 / 144 us): 6 -> 102 / 110 us (every resident
+// block builds its table at the same moment, nothing to overlap it with), 12 -> 98 / 105, 24 -> 95 / 102, 48 -> 101 / 111,
+// uncapped (a table per 16 KB of data) -> 106 / 117.  (A compile-time constant; tools/ build variants of it for A/B runs.)
+#ifndef QD_FINE_BLOCKS_PER_CU
+#define QD_FINE_BLOCKS_PER_CU 24
+#endif
+constexpr int kFineBlocksPerCu = QD_FINE_BLOCKS_PER_CU;
+constexpr size_t kCoarseTableBytes = (size_t)2 * kMaxPoints * sizeof(float) + (size_t)2 * (kCells + 4) * sizeof(int);   // 10272
+__host__ __device__ constexpr size_t point_table_bytes(int k, int fine = 0) {
     return k <= kSmallTable ? (size_t)2 * kSmallTable * sizeof(float)
-                            : (size_t)2 * kMaxPoints * sizeof(float) + (size_t)2 * (kCells + 4) * sizeof(int);
+                            : kCoarseTableBytes + (fine ? (size_t)kFineCells * 8 : 0);
 }
 
 // What the kernels pass around: a handle on the LDS table.  (Tried in round 3 and dropped: for small point sets the points
@@ -106,6 +131,7 @@ __host__ __device__ constexpr size_t point_table_bytes(int k) {
 // nonUniformQuantization call only.  profiles/r03_side_outputs.txt.)
 struct PointTable {
     const PointStore* s;
+    bool fine;
 };
 
 // cell of a scaled value: monotone non-decreasing in u (x256 is exact in fp32, then truncation and a
@@ -116,7 +142,13 @@ __device__ __forceinline__ int cell_of(float u) {
     return c < kCells - 1 ? c : kCells - 1;
 }
 
-__device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const float* pts, int k) {
+__device__ __forceinline__ int fine_cell_of(float u) {           // as cell_of: exact scaling by a power of two, monotone, NaN -> 0
+    const float t = u * (float)kFineCells;
+    int c = t > 0.0f ? (int)t : 0;
+    return c < kFineCells - 1 ? c : kFineCells - 1;
+}
+
+__device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const float* pts, int k, int fine = 0) {
     const int cap = k <= kSmallTable ? kSmallTable : kMaxPoints;
     // midpoints FIRST and the cell tables at a constant distance: the searches of the per-step call (midpoint rule) then
     // address LDS with compile-time offsets again, whatever the table size; only the points sit at a k-dependent offset
@@ -125,6 +157,7 @@ __device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const 
     T.pts = T.mid + cap;
     T.start = (lds_i32*)(T.mid + 2 * kMaxPoints);            // (k > 32 only, where cap == kMaxPoints)
     T.startp = T.start + (kCells + 4);
+    T.cell = (lds_u2*)(qd_dyn_lds + kCoarseTableBytes);      // (`fine` only)
     for (int j = threadIdx.x; j < k; j += blockDim.x) T.pts[j] = pts[j];
     __syncthreads();
     for (int j = threadIdx.x; j + 1 < k; j += blockDim.x) {
@@ -133,7 +166,7 @@ __device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const 
         T.mid[j] = T.pts[j] + d;             // k[:-1] + ...
     }
     __syncthreads();
-    if (k > 32) {
+    if (k > 32 && !fine) {                                   // (the fine table below replaces both coarse ones: `fine` is midpoint-rule only)
         // start[c] by binary search on the monotone predicate cell(mid_j) < c
         for (int c = threadIdx.x; c <= kCells; c += blockDim.x) {
             int lo = 0, n = k - 1;
@@ -151,7 +184,47 @@ __device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const 
         }
         __syncthreads();
     }
+    if (k > 32 && fine) {
+        // count the midpoints per fine cell (integer LDS atomics), exclusive scan over the cells, then the entries
+        lds_i32* cnt = (lds_i32*)T.cell;                     // the first kFineCells dwords of the entry array, for now
+        lds_i32* wsum = cnt + kFineCells;                    // wave totals of the scan (<= 16)
+        for (int c = threadIdx.x; c < kFineCells; c += blockDim.x) cnt[c] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j + 1 < k; j += blockDim.x)
+            __hip_atomic_fetch_add(&cnt[fine_cell_of(T.mid[j])], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        // thread t owns cells [t * per, (t + 1) * per); blockDim is 128, 256 or 1024: per = 16, 8, 2
+        const int per = kFineCells / (int)blockDim.x;
+        int mine[16];
+        int local = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { mine[q] = q < per ? cnt[threadIdx.x * per + q] : 0; local += mine[q]; }
+        int incl = local;                                    // inclusive scan over the lanes of the wave
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int o = __shfl_up(incl, sft);
+            incl += (int)(threadIdx.x & 63) >= sft ? o : 0;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();                                     // every thread has read its counters: the array may be overwritten
+        int base = incl - local;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+        __syncthreads();                                     // (wsum sits inside the entry array)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (q < per) {
+                const int n_here = mine[q];
+                u32x2 e;
+                e.x = (uint32_t)base | ((uint32_t)n_here << 16);
+                e.y = n_here > 0 ? __float_as_uint(T.mid[base]) : 0x7FC00000u;      // NaN: no midpoint, the compare is false
+                T.cell[threadIdx.x * per + q] = e;
+                base += n_here;
+            }
+        }
+        __syncthreads();
+    }
     C.s = &T;
+    C.fine = k > 32 && fine;
 }
 
 // #{ midpoints <= u }.  For many points the search is narrowed to the midpoints that fall in u's
@@ -159,6 +232,13 @@ __device__ __forceinline__ void load_points(PointTable& C, PointStore& T, const 
 // is monotone), so the count is exact whatever the point distribution; with roughly uniform points
 // the remaining range holds 0-2 midpoints instead of k-1 (LDS reads per element: ~4 instead of ~9
 // at k = 256, and fewer bank conflicts).
+__device__ __forceinline__ int midpoint_index_fine(const PointStore& T, float u) {
+    const u32x2 e = T.cell[fine_cell_of(u)];
+    const int s0 = (int)(e.x & 0xFFFFu), n_here = (int)(e.x >> 16);
+    int i = s0 + ((__uint_as_float(e.y) <= u) ? 1 : 0);                   // right for a cell with 0 or 1 midpoints
+    if (n_here > 1) i = s0 + count_before<true>(T.mid + s0, n_here, u);   // crowded cell: search inside it
+    return i;
+}
 __device__ __forceinline__ int midpoint_index(const PointStore& T, int k, float u) {
     if (k <= 32) return count_before<true>(T.mid, k - 1, u);
     const int c = cell_of(u);
@@ -202,7 +282,7 @@ __device__ __forceinline__ float transform(const KParams& p, const PointTable* T
     } else {
         float u = v;
         if (!p.prescaled) { u = v - b; u = u / a; }
-        const int i = assign_point(*T->s, p.k, p.assign_mode, u);
+        const int i = T->fine ? midpoint_index_fine(*T->s, u) : assign_point(*T->s, p.k, p.assign_mode, u);
         const float pt = T->s->pts[i];
         side = (float)i;
         float y = pt * a;
@@ -571,7 +651,7 @@ __global__ __launch_bounds__(256) void k_bucket_vec(KParams p) {
     PointStore Ts;
     PointTable Tc;
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
 
     constexpr int BPW = (64 / LPB) * U;           // buckets per wave tile
     constexpr int ROW = LPB * V * 4;              // elements per bucket
@@ -652,7 +732,7 @@ void k_bucket_chunk(KParams p, int m, int64_t nchunks) {
     PointStore Ts;
     PointTable Tc;
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
     // dynamic LDS: [point table (nearest-point mode)] then per wave: pairs[VMAX * 64], ab[256], 1/alpha[256]
     float2* chunk_lds = (float2*)(qd_dyn_lds + (MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -807,7 +887,7 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
     PointStore Ts;
     PointTable Tc;
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
     // dynamic LDS: [point table (nearest-point mode)] then per wave: vals[VMAX * 256] floats (+ side bytes)
     float2* chunk_lds = (float2*)(qd_dyn_lds + (MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -998,7 +1078,7 @@ void k_bucket_wave_any(KParams p, int64_t nbk, int64_t amask) {
     PointTable Tc;
     __shared__ float red[2][4][2];                         // [iteration parity][wave of the block][min, max]
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
     constexpr int GL = 64 * G;                             // lanes per bucket
     constexpr int GPB = 4 / G;                             // buckets per block and iteration
     const int lane = threadIdx.x & (GL - 1);               // lane inside the bucket's group
@@ -1154,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_bucket_groups(KParams p) {
     PointStore Ts;
     PointTable Tc;
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -1177,7 +1257,7 @@ __global__ __launch_bounds__(1024) void k_bucket_generic(KParams p) {
     PointTable Tc;
     __shared__ float red[32];
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -1300,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_single_apply(KParams p, const float* ab
     PointTable Tc;
     __shared__ float red[32];
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -1451,7 +1531,7 @@ void k_single_fused(KParams p, int slot_set, unsigned tag_min, unsigned tag_max,
     __shared__ float red[32];
     __shared__ int s_timed_out;
     const PointTable* T = &Tc;                             // (read only in the nearest-point mode)
-    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k);
+    if (MODE == MODE_NEAREST) load_points(Tc, Ts, p.pts, p.k, p.fine);
     Prep pp;
     pp.mean = p.mean ? *p.mean : 0.0f;
     pp.me = p.me;
@@ -1638,7 +1718,10 @@ int launch_bucketed(KParams& p, hipStream_t st) {
                          (MODE != MODE_NEAREST || p.idx == nullptr || p.idx_bytes != 8 || (((uintptr_t)p.idx) & 15) == 0) &&
                          (MODE != MODE_QDQ || p.lev8 == nullptr || (((uintptr_t)p.lev8) & 3) == 0);
     const int64_t nfull = p.n / p.row;                 // leading full buckets
-    const size_t tb = MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0;      // dynamic LDS of every launch: the point table
+    const size_t tb = MODE == MODE_NEAREST ? point_table_bytes(p.k, p.fine) : 0;      // dynamic LDS of every launch: the point table
+    // with the fine cell table the grid is capped (the kernels loop): the table is built once per resident block, not per tile
+    const int fine_cap = (MODE == MODE_NEAREST && p.fine) ? kFineBlocksPerCu * num_cus() : (1 << 30);
+    const size_t tbc = MODE == MODE_NEAREST ? point_table_bytes(p.k, 0) : 0;           // the chunk kernels': always the coarse table
     // k_bucket_chunk_any stages level / point indices that fit a byte in LDS (the same expression as in the kernel)
     const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 32);
 #define QD_VEC(LPB, V, U)                                                                       \
@@ -1646,8 +1729,13 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         p.nvec = nfull;                                                                         \
         constexpr int64_t bpw = (64 / LPB) * U;                                                 \
         const int64_t tiles = (nfull + bpw - 1) / bpw;                                          \
-        const int blocks = blocks_for(tiles, 4) + 1; /* +1: the block that owns the tail */     \
-        hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V, U>), dim3(blocks), dim3(256), tb, st, p); \
+        int blocks = blocks_for(tiles, 4) + 1; /* +1: the block that owns the tail */           \
+        /* the vector kernel hides the narrowed search behind 7 waves per SIMD up to 64 points (99 us against 104 us with */ \
+        /* the fine table on a capped grid); the kernels with fewer resident waves gain from 33 points on */ \
+        if (MODE == MODE_NEAREST && p.k <= 64) p.fine = 0;                                      \
+        if (MODE == MODE_NEAREST && p.fine && blocks > fine_cap) blocks = fine_cap;             \
+        hipLaunchKernelGGL((k_bucket_vec<MODE, LPB, V, U>), dim3(blocks), dim3(256),            \
+                           MODE == MODE_NEAREST ? point_table_bytes(p.k, p.fine) : 0, st, p);   \
         return check_launch();                                                                  \
     }
     if (aligned && p.nb > 1) {
@@ -1683,7 +1771,8 @@ int launch_bucketed(KParams& p, hipStream_t st) {
 #define QD_WAVE_ANY(V, G)                                                                                  \
     {                                                                                                      \
         const int64_t nbk = V > 16 ? nbk_whole : nbk_all;                                                  \
-        const int blocks = blocks_for(nbk > 0 ? nbk : 1, 4 / G);                                           \
+        int blocks = blocks_for(nbk > 0 ? nbk : 1, 4 / G);                                                 \
+        if (blocks > fine_cap) blocks = fine_cap;                                                          \
         hipLaunchKernelGGL((k_bucket_wave_any<MODE, V, G>), dim3(blocks), dim3(256), tb, st, p, nbk, amask); \
         return check_launch();                                                                             \
     }
@@ -1747,7 +1836,8 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         if (nchunks > 0) {
             const size_t lds = (size_t)2 * (kChunkV * 64 + 256 + 128) * sizeof(float2);   // two waves per block: pairs, (alpha, beta), 1/alpha
             const int blocks = blocks_for(nchunks, 2) + 1;                             // +1: the block that owns the tail
-            hipLaunchKernelGGL((k_bucket_chunk<MODE, kChunkV>), dim3(blocks), dim3(128), lds + tb, st, p, m, nchunks);
+            p.fine = 0;                                                                // the chunk kernels stage data in LDS: coarse table
+            hipLaunchKernelGGL((k_bucket_chunk<MODE, kChunkV>), dim3(blocks), dim3(128), lds + tbc, st, p, m, nchunks);
             return check_launch();
         }
     }
@@ -1767,7 +1857,8 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             // two waves: the staged chunk, + a byte per element when level / point indices (<= 255) are asked for
             const size_t lds = (size_t)2 * (kChunkV * 256 + (stage8 ? kChunkV * 64 : 0)) * sizeof(float);
             const int blocks = blocks_for(nchunks, 2) + 1;
-            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds + tb, st, p, m, nchunks, lead);
+            p.fine = 0;
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, kChunkV>), dim3(blocks), dim3(128), lds + tbc, st, p, m, nchunks, lead);
             return check_launch();
         }
     }
@@ -1776,17 +1867,18 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         if (nchunks > 0) {
             const size_t lds = (size_t)2 * (16 * 256 + (stage8 ? 16 * 64 : 0)) * sizeof(float);
             const int blocks = blocks_for(nchunks, 2) + 1;
-            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds + tb, st, p, 4, nchunks,
+            p.fine = 0;
+            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds + tbc, st, p, 4, nchunks,
                                p.row * 4 + 28 <= 16 * 256 ? 1 : 0);
             return check_launch();
         }
     }
     if (p.row <= 256) {                                  // 16 buckets per block, a DPP row each
-        hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16)), dim3(256), tb, st, p);
+        hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16) < fine_cap ? blocks_for(p.nb, 16) : fine_cap), dim3(256), tb, st, p);
     } else if (p.row <= 16384) {                         // 4 buckets per block, one wave each
-        hipLaunchKernelGGL((k_bucket_groups<MODE, 64>), dim3(blocks_for(p.nb, 4)), dim3(256), tb, st, p);
+        hipLaunchKernelGGL((k_bucket_groups<MODE, 64>), dim3(blocks_for(p.nb, 4) < fine_cap ? blocks_for(p.nb, 4) : fine_cap), dim3(256), tb, st, p);
     } else {
-        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(blocks_for(p.nb, 1)), dim3(1024), tb, st, p);
+        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(blocks_for(p.nb, 1) < fine_cap ? blocks_for(p.nb, 1) : fine_cap), dim3(1024), tb, st, p);
     }
     return check_launch();
 }
@@ -1804,7 +1896,7 @@ int fused_capacity() {                                         // blocks of k_si
         int per_cu = 0;
         hipFuncAttributes fa;
         const void* fn = (const void*)k_single_fused<MODE, V, W>;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, MODE == MODE_NEAREST ? point_table_bytes(kMaxPoints) : 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, MODE == MODE_NEAREST ? point_table_bytes(kMaxPoints, 1) : 0) != hipSuccess ||
             hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.localSizeBytes != 0 /* spills: not worth it */)
             per_cu = 0;
         (void)hipGetLastError();
@@ -1852,7 +1944,7 @@ int launch_single_fused(KParams& p, hipStream_t st) {
             const int slot = (int)(epoch % kFusedSlots);                                                   \
             p.nvec = 0;                                                                                    \
             hipLaunchKernelGGL((k_single_fused<MODE, V, W>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), \
-                               MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0, st, p, \
+                               MODE == MODE_NEAREST ? point_table_bytes(p.k, p.fine) : 0, st, p, \
                                slot, tag_min, tag_max, fmode >= 2 ? fmode - 1 : 0);          \
             return check_launch();                                                                         \
         }                                                                                                  \
@@ -1868,7 +1960,7 @@ int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int64_t kSmall = 16384;
     if (p.n <= kSmall) {                               // one block does both passes, one launch
         p.nvec = 0;
-        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(1), dim3(1024), MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0, st, p);
+        hipLaunchKernelGGL((k_bucket_generic<MODE>), dim3(1), dim3(1024), MODE == MODE_NEAREST ? point_table_bytes(p.k, p.fine) : 0, st, p);
         return check_launch();
     }
     Workspace w;
@@ -1895,7 +1987,8 @@ int launch_single(KParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
         }
     }
     const int blocks = blocks_for(p.n, 256 * 4 * 4);
-    hipLaunchKernelGGL((k_single_apply<MODE>), dim3(blocks), dim3(256), MODE == MODE_NEAREST ? point_table_bytes(p.k) : 0, st, p, ab,
+    hipLaunchKernelGGL((k_single_apply<MODE>), dim3(blocks < ((MODE == MODE_NEAREST && p.fine) ? kFineBlocksPerCu * num_cus() : (1 << 30)) ? blocks : kFineBlocksPerCu * num_cus()), dim3(256),
+                       MODE == MODE_NEAREST ? point_table_bytes(p.k, p.fine) : 0, st, p, ab,
                        w.minmax_part, nparts);
     return check_launch();
 }

@@ -526,6 +526,56 @@ def test_point_gradient_deterministic_and_within_1e6_on_every_path(bucket, k):
                          (bucket, k, name), n_terms=n)
 
 
+@pytest.mark.parametrize('k', [33, 64, 65, 200, 256, 1000])
+def test_fine_cell_table_with_crowded_and_degenerate_points(k):
+    """Above 32 points the pre-processed forward (midpoint rule) answers an element from a 2048-cell table when its cell holds
+    at most one midpoint and searches inside the cell otherwise (qd_transform.h).  Point sets that stress exactly that:
+    all points inside ONE cell, a bell-shaped crowd (what a percentile initialisation produces), duplicates, points ON cell
+    boundaries j / 2048, points outside [0, 1]; values on boundaries, on midpoints, below 0, above 1, +-inf and NaN -- on the
+    vector kernel (bucket 256), one wave per bucket (1000), the chunk kernels (100, 33: coarse table), lane groups (a short
+    tensor) and the single-bucket kernels.  Indices and values bit-identical to numpy's count of midpoints <= u
+    (ref: quant_functions.py:531-563)."""
+    lib = _lib.load()
+    rng = np.random.RandomState(k)
+    sets = {
+        'one cell': np.sort(0.5 + rng.rand(k) / 4096.0),
+        'bell': np.sort(np.clip(0.5 + 0.11 * rng.randn(k), 0.0, 1.0)),
+        'duplicates': np.sort(np.repeat(rng.rand((k + 3) // 4), 4)[:k]),
+        'on boundaries': np.sort(rng.choice(2049, size=k, replace=k > 2049) / 2048.0),
+        'outside': np.sort(np.concatenate([[-0.5, -1e-3], rng.rand(k - 4), [1.0 + 1e-3, 1.7]])),
+        'uniform': np.sort(rng.rand(k)),
+    }
+    n = 200003
+    u = rng.rand(n).astype(np.float32)
+    u[:2049] = (np.arange(2049) / 2048.0).astype(np.float32)                  # every cell boundary
+    u[3000:3008] = [-1.0, -0.0, 2.0, np.inf, -np.inf, np.nan, 1.0, 0.0]
+    ws = torch.empty(lib.qd_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for name, pts64 in sets.items():
+        pts = pts64.astype(np.float32)
+        mid = (pts[:-1] + (pts[1:] - pts[:-1]) / np.float32(2.0)).astype(np.float32)          # :533, fp32
+        uu = u.copy()
+        uu[4000:4000 + mid.size] = mid                                                         # values ON midpoints: ties go up
+        want_idx = np.searchsorted(mid, uu, side='right').astype(np.int64)
+        want_idx[np.isnan(uu)] = 0
+        want_q = pts[want_idx]
+        pd, ud = dev(pts), dev(uu)
+        for bucket, nn in ((256, n), (1000, n), (100, n), (33, n), (0, n), (0, 50000), (256, 700), (5000, n)):
+            nb = lib.qd_num_buckets(nn, bucket)
+            ab = torch.ones(2, nb, device=DEV)
+            ab[1].zero_()
+            for idx_bytes, dt in ((8, torch.int64), (1, torch.uint8)):
+                if idx_bytes == 1 and k > 256:
+                    continue
+                q = torch.full((nn,), float('nan'), device=DEV)
+                idx = torch.full((nn,), 77, dtype=dt, device=DEV)
+                _lib.check(lib.qd_nearest_point_f32(ud.data_ptr(), 1, pd.data_ptr(), k, 1, q.data_ptr(), idx.data_ptr(), idx_bytes, nn, bucket,
+                                                    ab[0].data_ptr(), ab[1].data_ptr(), None, 0, 0.0, ws.data_ptr(), ws.numel(), st))
+                got_i = host(idx).astype(np.int64)
+                assert np.array_equal(got_i, want_idx[:nn]), (k, name, bucket, nn, idx_bytes, np.flatnonzero(got_i != want_idx[:nn])[:5])
+                assert np.array_equal(host(q), want_q[:nn], equal_nan=True), (k, name, bucket, nn, idx_bytes)
+
+
 def test_search_sorted_handle_query():
     from quantization.quant_functions import SearchSorted
     x = np.random.RandomState(0).rand(10000).astype(np.float32)
