@@ -44,25 +44,71 @@ __global__ __launch_bounds__(256) void k_mean_final(const double* part, int npar
 }
 
 // ---- inverse scaling (quant_functions.py:131-152) --------------------------------------------
+// y = u * alpha_b + beta_b (+ mean), three separately rounded operations, a plain stream at ANY bucket size from 4 elements
+// up: every lane takes float4s in memory order (kInvU in flight); the float4's first element lies in bucket b0 = e / row --
+// one division per lane, then advanced incrementally -- and the others in b0 or b0 + 1, so two (alpha, beta) pairs per
+// float4, served by L1 / L2 as neighbouring lanes ask for the same buckets.  (Round 2 divided per float4 and sent every
+// bucket size that is not a multiple of 4 down the scalar tail loop.)
+// TWO = false: the bucket size is a multiple of 4 (or there is one bucket), a float4 never straddles two buckets: one pair.
+constexpr int kInvU = 4;
+template <bool TWO>
 __global__ __launch_bounds__(256) void k_inv_scale(const float* u, float* y, int64_t n, int64_t row, int64_t nb,
                                                    const float* alpha, const float* beta, const float* mean) {
     const float m = mean ? *mean : 0.0f;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    const bool vec = (((((uintptr_t)u) | ((uintptr_t)y)) & kDataAlign) == 0) && (nb == 1 || (row & 3) == 0);
+    const bool vec = (((((uintptr_t)u) | ((uintptr_t)y)) & kDataAlign) == 0) && (nb == 1 || row >= 4);
     int64_t done = 0;
     if (vec) {
-        const int64_t n4 = n >> 2;
-        for (int64_t i = tid; i < n4; i += nth) {
-            const int64_t bkt = nb == 1 ? 0 : (i << 2) / row;
-            const float a = alpha[bkt], b = beta[bkt];
-            f4 v = __builtin_nontemporal_load((const f4*)u + i);
-            f4 r;
-            r.x = v.x * a; r.x = r.x + b; r.x = r.x + m;
-            r.y = v.y * a; r.y = r.y + b; r.y = r.y + m;
-            r.z = v.z * a; r.z = r.z + b; r.z = r.z + m;
-            r.w = v.w * a; r.w = r.w + b; r.w = r.w + m;
-            __builtin_nontemporal_store(r, (f4*)y + i);
+        // one CONTIGUOUS 4 KiB tile per wave and step (lane l holds float4 tile * 256 + 64 q + l), as the vector kernels
+        // stream: four far-apart streams per lane (float4 i, i + nth, ...) measured 6 % slower -- 90.6 us against 85.5 us
+        const int64_t n4 = n >> 2, last_b = nb - 1;
+        const int lane = threadIdx.x & 63;
+        const int64_t wave = uniform_wave_index(), nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+        const int64_t ntiles = (n4 + 255) >> 8;
+        const int64_t span = nb == 1 ? ((int64_t)1 << 62) : row;
+        const int64_t dq = nb == 1 ? 0 : 256 / row, dr = nb == 1 ? 0 : 256 % row;      // 64 float4 = 256 elements further
+        const bool small = n < ((int64_t)1 << 31);
+        for (int64_t t = wave; t < ntiles; t += nwaves) {
+            const int64_t base = (t << 8) + lane;                       // this lane's first float4 of the tile
+            int64_t bkt = 0, rem = 0;
+            if (nb > 1) {
+                if (small) { const uint32_t e = (uint32_t)(base << 2), rw = (uint32_t)row; bkt = e / rw; rem = e - (uint32_t)bkt * rw; }
+                else { bkt = (base << 2) / row; rem = (base << 2) - bkt * row; }
+            }
+            f4 v[kInvU];
+            float a0[kInvU], a1[kInvU], b0[kInvU], b1[kInvU];
+            int split[kInvU];
+#pragma unroll
+            for (int q = 0; q < kInvU; ++q) {
+                const int64_t ii = base + 64 * q;
+                v[q] = __builtin_nontemporal_load((const f4*)u + (ii < n4 ? ii : n4 - 1));       // always issued, clamped
+                const int64_t bb = bkt < last_b ? bkt : last_b, bn = bkt + 1 < last_b ? bkt + 1 : last_b;
+                a0[q] = alpha[bb]; b0[q] = beta[bb];
+                a1[q] = TWO ? alpha[bn] : a0[q]; b1[q] = TWO ? beta[bn] : b0[q];
+                const int64_t left = span - rem;
+                split[q] = (!TWO || left >= 4) ? 4 : (int)left;
+                bkt += dq; rem += dr;
+                if (rem >= span) { rem -= span; ++bkt; }
+            }
+#pragma unroll
+            for (int q = 0; q < kInvU; ++q) {
+                const int64_t ii = base + 64 * q;
+                if (ii < n4) {
+                    const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool first = c < split[q];
+                        float r = x[c] * (first ? a0[q] : a1[q]);
+                        r = r + (first ? b0[q] : b1[q]);
+                        r = r + m;
+                        o[c] = r;
+                    }
+                    const f4 rr = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(rr, (f4*)y + ii);
+                }
+            }
         }
         done = n4 << 2;
     }
@@ -818,8 +864,11 @@ int qd_inv_scale_f32(const float* u, float* y, int64_t n, int64_t bucket, const 
     if (n == 0) return 0;
     int64_t nb, row;
     geometry(n, bucket, nb, row);
-    const int blocks = blocks_for(n, 256 * 4 * 4);
-    hipLaunchKernelGGL(k_inv_scale, dim3(blocks), dim3(256), 0, (hipStream_t)stream, u, y, n, row, nb, alpha, beta,
+    const int blocks = blocks_for(n, 256 * 4 * 4);          // one 4 KiB tile per wave
+    if (nb == 1 || (row & 3) == 0)
+        hipLaunchKernelGGL(k_inv_scale<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, u, y, n, row, nb, alpha, beta, mean);
+    else
+        hipLaunchKernelGGL(k_inv_scale<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, u, y, n, row, nb, alpha, beta,
                        mean);
     return check_launch();
 }

@@ -257,6 +257,13 @@ def test_other_modes_at_chunk_sizes(bucket):
         assert np.array_equal(host(sfn.alpha).reshape(-1), r2['alpha']), (bucket, n)
         if n % bucket:                                               # padding = the scaled last element
             assert np.all(host(u).reshape(-1)[n:] == host(u).reshape(-1)[n - 1])
+        # K3 at the same bucket size (float4 stream with a per-element bucket choice): bit-exact against the oracle's
+        # inverse of the oracle's u
+        back = sfn.inv_scale_down(u)
+        nbk = -(-n // bucket)
+        u_pad = np.concatenate([r2['u'], np.full(nbk * bucket - n, r2['u'][-1], np.float32)]).reshape(nbk, bucket)
+        want_back = onp.inv_scale_down(u_pad, r2['alpha'].reshape(nbk, 1), r2['beta'].reshape(nbk, 1), 0.0, n, (n,))
+        assert np.array_equal(host(back).reshape(-1), np.asarray(want_back, np.float32).reshape(-1)), (bucket, n, 'inv_scale_down')
         # the pre-processed forward (u resident, midpoint rule, 64 points: the grid-narrowed search) and the point gradient
         pts64 = np.sort(rng.rand(64)).astype(np.float32)
         fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=xd)

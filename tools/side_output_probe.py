@@ -59,6 +59,10 @@ idx64 = [torch.empty(N, dtype=torch.int64, device=dev) for _ in range(2)]
 for b in buckets:
     timeit('K1 quantize bucket %d' % b, lambda i, b=b: lib.qd_uniform_f32(xs[i % R].data_ptr(), qs[i % R].data_ptr(), N, b, 16, None, None,
                                                                        None, None, 0, 0.0, 0, 0, ws.data_ptr(), ws.numel(), st), 8)
+    nbk = lib.qd_num_buckets(N, b)
+    ab3 = torch.rand(2, nbk, device=dev)
+    timeit('K3 inv_scale_down bucket %d' % b, lambda i, b=b: lib.qd_inv_scale_f32(xs[i % R].data_ptr(), qs[i % R].data_ptr(), N, b, ab3[0].data_ptr(),
+                                                                             ab3[1].data_ptr(), None, st), 8)
     timeit('L8 quantize + uint8 levels bucket %d' % b,
            lambda i, b=b: lib.qd_uniform_f32(xs[i % R].data_ptr(), qs[i % R].data_ptr(), N, b, 16, None, None, levs[i % R].data_ptr(), None, 0, 0.0,
                                              0, 0, ws.data_ptr(), ws.numel(), st), 9)
