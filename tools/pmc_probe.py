@@ -52,7 +52,7 @@ record('K4 nonUniform k=4 int64 idx', 'k_bucket_vec<2, 16, 4, 1>', 16 * N,
 fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=xs[i]) for i in range(3)]
 # (preprocess ran K2 three more times)
 counts['k_bucket_vec<1, 16, 4, 1>'] = counts.get('k_bucket_vec<1, 16, 4, 1>', 0) + 4   # + sf.scale_down(xs[0]) above
-record('K5 diff-quant forward k=4 u8 idx', 'k_bucket_vec<2, 16, 4, 1>', 9 * N, lambda i: keep.append(fns[i].forward(None, pts)))
+record('K5 diff-quant forward k=4 u8 idx', 'k_nearest_prescaled_stream<false>', 9 * N, lambda i: keep.append(fns[i].forward(None, pts)))
 record('K6 point gradient k=4 u8 idx', 'k_point_grad_fast<4, 1, true', 5 * N, lambda i: keep.append(fns[i].backward(gs[i])[1]))
 fq = quantization.uniformQuantization_variable(16, bucket_size=256)
 
@@ -68,8 +68,9 @@ pk = codec.pack_uniform(xs[0], 16, 256)
 counts['k_pack_vec<16, 4, 4>'] += 1
 record('UPK unpack 4-bit', 'k_unpack<4>', int(4.5 * N), lambda i: keep.append(pk.unpack()))
 # round 3: the calls with a side output at the bucket sizes of the chunk kernels
-for b, kern4, kern5 in ((100, 'k_bucket_chunk<2, 8>', 'k_bucket_chunk<2, 8>'), (33, 'k_bucket_chunk_any<2, 8>', 'k_bucket_chunk_any<2, 8>'),
-                        (250, 'k_bucket_chunk_any<2, 8>', 'k_bucket_chunk_any<2, 8>')):
+# (K5 -- the pre-processed forward -- is the float4 stream kernel at every bucket size: <true> when a float4 can straddle buckets)
+for b, kern4, kern5 in ((100, 'k_bucket_chunk<2, 8>', 'k_nearest_prescaled_stream<false>'), (33, 'k_bucket_chunk_any<2, 8>', 'k_nearest_prescaled_stream<true>'),
+                        (250, 'k_bucket_chunk_any<2, 8>', 'k_nearest_prescaled_stream<true>')):
     record('K4 nonUniform k=4 int64 idx bucket %d' % b, kern4, 16 * N,
            lambda i, b=b: keep.append(quantization.nonUniformQuantization(xs[i], pts, bucket_size=b)[:2]))
     fb = [quantization.nonUniformQuantization_variable(bucket_size=b, pre_process_tensors=True, tensor=xs[i + 3]) for i in range(3)]

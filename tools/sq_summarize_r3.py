@@ -20,7 +20,7 @@ for tag in ('prev', 'cur'):
     per = collections.OrderedDict()
     for r in csv.DictReader(open(cc[0])):
         name = r['Kernel_Name']
-        if 'k_bucket' not in name:
+        if 'k_bucket' not in name and 'k_nearest' not in name:
             continue
         per.setdefault(int(r['Dispatch_Id']), {'name': name.split('::')[-1].split('(')[0]})[r['Counter_Name']] = float(r['Counter_Value'])
     ids = sorted(per)
