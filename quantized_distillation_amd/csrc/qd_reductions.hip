@@ -245,9 +245,31 @@ struct PgBins {
     }
 };
 
-template <int KR, int IDXB, bool BUCKETED, int U, bool MERGE>
+// The buckets of the float4s a lane visits -- tid, tid + nth, tid + 2 nth, ... in that order -- at ANY bucket size from 4
+// elements up: one division per lane at the start, then (bucket, offset) advanced by 4 nth elements per step.  A float4
+// touches at most two buckets: the alphas of both and the number of its elements that lie in the first one.
+struct BucketWalk {
+    int64_t bkt, rem, dq, dr, row, last;
+    __device__ __forceinline__ void init(int64_t tid, int64_t nth, int64_t row_, int64_t nb) {
+        row = row_; last = nb - 1;
+        bkt = (tid << 2) / row; rem = (tid << 2) % row;
+        dq = (nth << 2) / row; dr = (nth << 2) % row;
+    }
+    __device__ __forceinline__ void next(const float* alpha, float& a0, float& a1, int& split) {
+        const int64_t bb = bkt < last ? bkt : last, bn = bkt + 1 < last ? bkt + 1 : last;
+        a0 = alpha[bb]; a1 = alpha[bn];
+        const int64_t left = row - rem;
+        split = left < 4 ? (int)left : 4;
+        bkt += dq; rem += dr;
+        if (rem >= row) { rem -= row; ++bkt; }
+    }
+};
+
+// BK: 0 = one alpha for the tensor, 1 = bucket = element >> row_shift (power-of-two buckets), 2 = any bucket size >= 4
+// (BucketWalk: non-power-of-two sizes ran on the scalar kernel below before: 82-126 us against 54-58 us)
+template <int KR, int IDXB, int BK, int U, bool MERGE>
 __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const void* idx, const float* alpha, int64_t n,
-                                                         int row_shift, int k, float* part /* [grid][k] */) {
+                                                         int row_shift, int64_t row, int64_t nb, int k, float* part /* [grid][k] */) {
     // KR == 0: bins[k][BS] with BS = blockDim.x (256 for k <= 128, 128 for k <= 256, 64 for k <= 512:
     // the table is at most 128 KiB of the CU's 160 KiB LDS); KR > 0: [4][KR]
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -260,9 +282,12 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
     }
     PgBins<KR> B;
     B.init(lds + threadIdx.x, BS);
-    const float a_single = BUCKETED ? 0.0f : alpha[0];
+    const float a_single = BK != 0 ? 0.0f : alpha[0];
     const int64_t n4 = n >> 2;
-    auto load4 = [&](int64_t i, f4& gv, int (&id)[4], float& a) {
+    BucketWalk walk;
+    if (BK == 2) walk.init(tid, nth, row, nb);
+    struct A2 { float a0, a1; int split; };
+    auto load4 = [&](int64_t i, f4& gv, int (&id)[4], A2& a) {
         gv = __builtin_nontemporal_load((const f4*)g + i);
         if (IDXB == 8) {
             const l2 p0 = __builtin_nontemporal_load((const l2*)idx + 2 * i);
@@ -272,10 +297,16 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
             const uint32_t pk = __builtin_nontemporal_load((const uint32_t*)idx + i);
             id[0] = pk & 255; id[1] = (pk >> 8) & 255; id[2] = (pk >> 16) & 255; id[3] = pk >> 24;
         }
-        a = BUCKETED ? alpha[(i << 2) >> row_shift] : a_single;
+        if (BK == 2) {
+            walk.next(alpha, a.a0, a.a1, a.split);          // (load4 is called for i = tid, tid + nth, ... in this order)
+        } else {
+            a.a0 = BK == 1 ? alpha[(i << 2) >> row_shift] : a_single;
+            a.a1 = a.a0; a.split = 4;
+        }
     };
-    auto accumulate = [&](const f4& gv, const int (&id)[4], float a) {
-        const float m[4] = {gv.x * a, gv.y * a, gv.z * a, gv.w * a};     // one fp32 multiply each, :495
+    auto accumulate = [&](const f4& gv, const int (&id)[4], const A2& a) {
+        const float m[4] = {gv.x * (BK == 2 && a.split < 1 ? a.a1 : a.a0), gv.y * (BK == 2 && a.split < 2 ? a.a1 : a.a0),
+                            gv.z * (BK == 2 && a.split < 3 ? a.a1 : a.a0), gv.w * (BK == 2 && a.split < 4 ? a.a1 : a.a0)};   // one fp32 multiply each, :495
         if (KR == 0 && MERGE) {
             B.add4_merged(id, m);
         } else {
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
     };
     int64_t i = tid;
     for (; i + (int64_t)(U - 1) * nth < n4; i += (int64_t)U * nth) {     // U independent float4 in flight per lane
-        f4 gv[U]; int id[U][4]; float a[U];
+        f4 gv[U]; int id[U][4]; A2 a[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) load4(i + (int64_t)u * nth, gv[u], id[u], a[u]);
         // without this the scheduler sinks every load to its first use (to save registers) and the loop pays
@@ -297,13 +328,13 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
         for (int u = 0; u < U; ++u) accumulate(gv[u], id[u], a[u]);
     }
     for (; i < n4; i += nth) {
-        f4 ga; int ia[4]; float sa;
+        f4 ga; int ia[4]; A2 sa;
         load4(i, ga, ia, sa);
         accumulate(ga, ia, sa);
     }
     for (int64_t e = (n4 << 2) + tid; e < n; e += nth) {     // n % 4 leftover elements
         const int id = IDXB == 8 ? (int)((const int64_t*)idx)[e] : (int)((const uint8_t*)idx)[e];
-        B.add(id, g[e] * (BUCKETED ? alpha[e >> row_shift] : a_single));
+        B.add(id, g[e] * (BK == 2 ? alpha[e / row] : (BK == 1 ? alpha[e >> row_shift] : a_single)));
     }
     if (KR > 0) {
         const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -343,9 +374,9 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
 // turn token round robin through LDS: a wave issues the loads of batch i+2, waits for its turn, updates the table with
 // batch i, hands the token on, and prepares batch i+1 while the other waves take their turns.  No block barriers in the
 // loop, no atomics on the table, and deterministic: the update order is fixed (wave 0, 1, ..., G-1, batch by batch).
-template <int IDXB, bool BUCKETED, int U, int G>
+template <int IDXB, int BK, int U, int G>
 __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, const void* idx, const float* alpha, int64_t n,
-                                                            int row_shift, int k, float* part /* [grid][k] */) {
+                                                            int row_shift, int64_t row, int64_t nb, int k, float* part /* [grid][k] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [k][64]
     __shared__ int turn;
     constexpr int C = 64;
@@ -353,14 +384,16 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
     float* col = lds + (threadIdx.x & 63);
     for (int j = threadIdx.x; j < k * C; j += blockDim.x) lds[j] = 0.0f;
     if (threadIdx.x == 0) turn = 0;
-    const float a_single = BUCKETED ? 0.0f : alpha[0];
+    const float a_single = BK != 0 ? 0.0f : alpha[0];
     const int64_t n4 = n >> 2;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     const int64_t iters = (n4 + (int64_t)U * nth - 1) / ((int64_t)U * nth);   // the same for every wave: the token must circulate
+    BucketWalk walk;
+    if (BK == 2) walk.init(tid, nth, row, nb);
     int id[U][4];
     float sm[U][4];
-    f4 gv[U]; uint32_t pk[U]; l2 p0[U], p1[U]; float al[U];             // the raw batch in flight
+    f4 gv[U]; uint32_t pk[U]; l2 p0[U], p1[U]; float al[U], al1[U]; int spl[U];   // the raw batch in flight
     auto issue = [&](int64_t it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -373,7 +406,12 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
             } else {
                 pk[u] = __builtin_nontemporal_load((const uint32_t*)idx + i);
             }
-            al[u] = BUCKETED ? alpha[(i << 2) >> row_shift] : a_single;
+            if (BK == 2) {
+                walk.next(alpha, al[u], al1[u], spl[u]);    // (issue() runs for it = 0, 1, 2, ... in this order)
+            } else {
+                al[u] = BK == 1 ? alpha[(i << 2) >> row_shift] : a_single;
+                al1[u] = al[u]; spl[u] = 4;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);                  // issued here, not sunk to the first use
     };
@@ -388,8 +426,10 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
                 id[u][0] = pk[u] & 255; id[u][1] = (pk[u] >> 8) & 255; id[u][2] = (pk[u] >> 16) & 255; id[u][3] = pk[u] >> 24;
             }
             const float z = 0.0f;
-            const float m0 = live ? gv[u].x * al[u] : z, m1 = live ? gv[u].y * al[u] : z;  // one fp32 multiply each, :495
-            const float m2 = live ? gv[u].z * al[u] : z, m3 = live ? gv[u].w * al[u] : z;
+            const float m0 = live ? gv[u].x * (BK == 2 && spl[u] < 1 ? al1[u] : al[u]) : z;   // one fp32 multiply each, :495
+            const float m1 = live ? gv[u].y * (BK == 2 && spl[u] < 2 ? al1[u] : al[u]) : z;
+            const float m2 = live ? gv[u].z * (BK == 2 && spl[u] < 3 ? al1[u] : al[u]) : z;
+            const float m3 = live ? gv[u].w * (BK == 2 && spl[u] < 4 ? al1[u] : al[u]) : z;
             const bool e01 = id[u][0] == id[u][1], e02 = id[u][0] == id[u][2], e03 = id[u][0] == id[u][3];
             const bool e12 = id[u][1] == id[u][2], e13 = id[u][1] == id[u][3], e23 = id[u][2] == id[u][3];
             // every element whose index matches gets the same fixed-order sum: equal addresses are written with equal values
@@ -432,7 +472,7 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
     if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
         const int64_t e = (n4 << 2) + threadIdx.x;
         const int ide = IDXB == 8 ? (int)((const int64_t*)idx)[e] : (int)((const uint8_t*)idx)[e];
-        col[ide * C] += g[e] * (BUCKETED ? alpha[e >> row_shift] : a_single);
+        col[ide * C] += g[e] * (BK == 2 ? alpha[e / row] : (BK == 1 ? alpha[e >> row_shift] : a_single));
     }
     __syncthreads();
     // 4 threads per bin, 16 columns each, rotated start (bank-conflict free), then a fixed fold
@@ -920,7 +960,9 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     const bool pow2 = nb == 1 || (row & (row - 1)) == 0;
     if (nb > 1 && pow2) while (((int64_t)1 << row_shift) < row) ++row_shift;
     const bool idx_ok = idx_bytes == 8 ? ((((uintptr_t)idx) & 15) == 0) : ((((uintptr_t)idx) & 3) == 0);
-    const bool fast = k <= 512 && pow2 && idx_ok && ((((uintptr_t)g) & kDataAlign) == 0) && (nb == 1 || row >= 4);
+    // (any bucket size from 4 elements up: BK = 2 walks the buckets; only shorter buckets and misaligned tensors are left
+    // to the scalar kernel)
+    const bool fast = k <= 512 && idx_ok && ((((uintptr_t)g) & kDataAlign) == 0) && (nb == 1 || row >= 4);
     if (fast) {
         // k <= 4: register bins; otherwise an LDS table [k][threads] of lane-private columns
         const int threads = k <= 128 ? 256 : (k <= 256 ? 128 : 64);
@@ -940,7 +982,7 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
             if (lds_bytes > 64 * 1024)                                                                              \
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(KR > 0 ? 256 : threads), lds_bytes, st, g, idx, alpha, n,   \
-                               row_shift, k, w.pg_part);                                                            \
+                               row_shift, row, nb, k, w.pg_part);                                                   \
         }
 #define QD_PG_K(IDXB, BK)                                                                                           \
         {                                                                                                           \
@@ -959,11 +1001,11 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
                 if constexpr (IDXB == 8) {                                                                           \
                     auto kern = k_point_grad_turns<IDXB, BK, 4, 4>;                                                  \
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); \
-                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, k, w.pg_part); \
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, row, nb, k, w.pg_part); \
                 } else {                                                                                             \
                     auto kern = k_point_grad_turns<IDXB, BK, 8, 4>;                                                  \
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); \
-                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, k, w.pg_part); \
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, row, nb, k, w.pg_part); \
                 }                                                                                                    \
             }                                                                                                       \
         }
@@ -972,8 +1014,8 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
         // column under a table above 64 KiB -- one block per CU -- measured 66.6 / 110-121 us at k = 128 / 256 with 8 .. 32
         // float4 in flight per lane: those waves are bound by their own VALU + LDS round trips.)
         constexpr int kTurnsBlocksPerCu = 2;
-        if (idx_bytes == 8) { if (nb > 1) QD_PG_K(8, true) else QD_PG_K(8, false) }
-        else { if (nb > 1) QD_PG_K(1, true) else QD_PG_K(1, false) }
+        if (idx_bytes == 8) { if (nb == 1) QD_PG_K(8, 0) else if (pow2) QD_PG_K(8, 1) else QD_PG_K(8, 2) }
+        else { if (nb == 1) QD_PG_K(1, 0) else if (pow2) QD_PG_K(1, 1) else QD_PG_K(1, 2) }
 #undef QD_PG_K
 #undef QD_PG
     } else {

@@ -4,6 +4,8 @@
     K5   pre-processed forward (midpoint)   u -> q + uint8 indices             9 B/element
     L8   quantize + uint8 level indices     x -> q + levels (C ABI)            9 B/element
     K1   quantize alone, for reference                                         8 B/element
+    K3   inv_scale_down                     u -> y                             8 B/element
+    K6   point gradient                     g + uint8 indices -> k sums        5 B/element
 Usage: python tools/side_output_probe.py [buckets, comma separated] [k values, comma separated]"""
 import os
 import sys
@@ -81,3 +83,11 @@ for b in buckets:
                    lambda i, b=b: lib.qd_nearest_point_f32(us[i % 2].data_ptr(), 1, pts.data_ptr(), k, 1, qs[i % R].data_ptr(), levs[i % R].data_ptr(), 1,
                                                            N, b, ab[0].data_ptr(), ab[1].data_ptr(), None, 0, 0.0, ws.data_ptr(), ws.numel(), st), 9)
             del us
+            gs = [torch.randn(N, device=dev) for _ in range(2)]
+            gp = torch.empty(k, device=dev)
+            levs[0].random_(0, k)
+            levs[1].random_(0, k)
+            timeit('K6 point gradient k=%d uint8 idx bucket %d' % (k, b),
+                   lambda i, b=b: lib.qd_point_grad_f32(gs[i % 2].data_ptr(), levs[i % 2].data_ptr(), 1, ab[0].data_ptr(), N, b, k, gp.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), st), 5)
+            del gs
