@@ -207,6 +207,20 @@ __global__ __launch_bounds__(256) void k_arg_final(const float* pv, const int64_
 //            read-add-write (no atomics: LDS float atomics retire ~1 lane per 3 cycles on gfx950,
 //            measured 390 us for the 64 Mi-element tensor); k <= 64.
 // Both are deterministic: fixed per-lane order, fixed fold order.
+// s[j] = the in-order sum of the elements i <= j of a float4 that share element j's index.  The four bins are read before
+// any is written and the LDS writes of a wave complete in program order, so the LAST element of a group of duplicates
+// -- whose s is the group's whole sum, added in element order -- is the one that stays: 6 compares, 6 selects, 6 adds
+// (giving every duplicate the full sum, as round 2 did, costs 12 + 12).
+__device__ __forceinline__ void merged_prefix_sums(const int (&id)[4], const float (&m)[4], float (&s)[4]) {
+    const bool e01 = id[0] == id[1], e02 = id[0] == id[2], e03 = id[0] == id[3];
+    const bool e12 = id[1] == id[2], e13 = id[1] == id[3], e23 = id[2] == id[3];
+    const float z = 0.0f;
+    s[0] = m[0];
+    s[1] = (e01 ? m[0] : z) + m[1];
+    s[2] = ((e02 ? m[0] : z) + (e12 ? m[1] : z)) + m[2];
+    s[3] = (((e03 ? m[0] : z) + (e13 ? m[1] : z)) + (e23 ? m[2] : z)) + m[3];
+}
+
 template <int KR>
 struct PgBins {
     float acc[KR > 0 ? KR : 1];
@@ -227,39 +241,34 @@ struct PgBins {
         }
     }
     // four elements at once, for the large tables that leave one or two waves per CU: the four reads are
-    // independent (one LDS round trip instead of four dependent ones); lanes' duplicates are resolved in
-    // registers -- every element whose index matches gets the same fixed-order sum, so equal addresses are
-    // written with equal values and the result does not depend on the write order.
+    // independent (one LDS round trip instead of four dependent ones); a lane's duplicates are resolved in
+    // registers (merged_prefix_sums below) and the four writes go out in element order.
     __device__ __forceinline__ void add4_merged(const int (&id)[4], const float (&m)[4]) {
         float* a0 = col + id[0] * stride; float* a1 = col + id[1] * stride;
         float* a2 = col + id[2] * stride; float* a3 = col + id[3] * stride;
         const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
-        const bool e01 = id[0] == id[1], e02 = id[0] == id[2], e03 = id[0] == id[3];
-        const bool e12 = id[1] == id[2], e13 = id[1] == id[3], e23 = id[2] == id[3];
-        const float z = 0.0f;
-        const float s0 = ((m[0] + (e01 ? m[1] : z)) + (e02 ? m[2] : z)) + (e03 ? m[3] : z);
-        const float s1 = (((e01 ? m[0] : z) + m[1]) + (e12 ? m[2] : z)) + (e13 ? m[3] : z);
-        const float s2 = (((e02 ? m[0] : z) + (e12 ? m[1] : z)) + m[2]) + (e23 ? m[3] : z);
-        const float s3 = (((e03 ? m[0] : z) + (e13 ? m[1] : z)) + (e23 ? m[2] : z)) + m[3];
-        *a0 = c0 + s0; *a1 = c1 + s1; *a2 = c2 + s2; *a3 = c3 + s3;
+        float s[4];
+        merged_prefix_sums(id, m, s);
+        *a0 = c0 + s[0]; *a1 = c1 + s[1]; *a2 = c2 + s[2]; *a3 = c3 + s[3];
     }
 };
 
 // The buckets of the float4s a lane visits -- tid, tid + nth, tid + 2 nth, ... in that order -- at ANY bucket size from 4
 // elements up: one division per lane at the start, then (bucket, offset) advanced by 4 nth elements per step.  A float4
 // touches at most two buckets: the alphas of both and the number of its elements that lie in the first one.
+// 32-bit state: the host takes this path only with fewer than 2^30 buckets of fewer than 2^30 elements.
 struct BucketWalk {
-    int64_t bkt, rem, dq, dr, row, last;
+    int bkt, rem, dq, dr, row, last;
     __device__ __forceinline__ void init(int64_t tid, int64_t nth, int64_t row_, int64_t nb) {
-        row = row_; last = nb - 1;
-        bkt = (tid << 2) / row; rem = (tid << 2) % row;
-        dq = (nth << 2) / row; dr = (nth << 2) % row;
+        row = (int)row_; last = (int)(nb - 1);
+        bkt = (int)((tid << 2) / row_); rem = (int)((tid << 2) % row_);
+        dq = (int)((nth << 2) / row_); dr = (int)((nth << 2) % row_);
     }
     __device__ __forceinline__ void next(const float* alpha, float& a0, float& a1, int& split) {
-        const int64_t bb = bkt < last ? bkt : last, bn = bkt + 1 < last ? bkt + 1 : last;
+        const int bb = bkt < last ? bkt : last, bn = bkt + 1 < last ? bkt + 1 : last;     // (clamped loads past the end are dead)
         a0 = alpha[bb]; a1 = alpha[bn];
-        const int64_t left = row - rem;
-        split = left < 4 ? (int)left : 4;
+        const int left = row - rem;
+        split = left < 4 ? left : 4;
         bkt += dq; rem += dr;
         if (rem >= row) { rem -= row; ++bkt; }
     }
@@ -273,9 +282,11 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
     // KR == 0: bins[k][BS] with BS = blockDim.x (256 for k <= 128, 128 for k <= 256, 64 for k <= 512:
     // the table is at most 128 KiB of the CU's 160 KiB LDS); KR > 0: [4][KR]
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int BS = blockDim.x;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const int BS = blockDim.x;                              // 64 / 128 / 256
+    const unsigned tx = threadIdx.x;
+    const int64_t bbase = (int64_t)blockIdx.x * BS;         // block-uniform: lane 0's first float4
+    const int64_t tid = bbase + tx;
+    const int64_t nth = (int64_t)gridDim.x * BS;
     if (KR == 0) {
         for (int j = threadIdx.x; j < k * BS; j += BS) lds[j] = 0.0f;
         __syncthreads();
@@ -304,6 +315,29 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
             a.a1 = a.a0; a.split = 4;
         }
     };
+    // the same for the float4 of lane tx of a block whose lane 0 is at the block-uniform index ub (a multiple of BS): scalar
+    // base addresses + one loop-invariant lane offset each, no 64-bit vector arithmetic.  Power-of-two buckets: BS divides
+    // ub and tx < BS, so bucket(ub + tx) = (ub >> sh) + (tx >> sh) for every shift.
+    const int sh = BK == 1 ? row_shift - 2 : 0;
+    const unsigned txs = sh < 31 ? tx >> sh : 0u;
+    auto load4u = [&](int64_t ub, f4& gv, int (&id)[4], A2& a) {
+        gv = __builtin_nontemporal_load((const f4*)g + ub + tx);
+        if (IDXB == 8) {
+            const l2* ip = (const l2*)idx + 2 * ub;
+            const l2 p0 = __builtin_nontemporal_load(ip + 2 * tx);
+            const l2 p1 = __builtin_nontemporal_load(ip + 2 * tx + 1);
+            id[0] = (int)p0.x; id[1] = (int)p0.y; id[2] = (int)p1.x; id[3] = (int)p1.y;
+        } else {
+            const uint32_t pk = __builtin_nontemporal_load((const uint32_t*)idx + ub + tx);
+            id[0] = pk & 255; id[1] = (pk >> 8) & 255; id[2] = (pk >> 16) & 255; id[3] = pk >> 24;
+        }
+        if (BK == 2) {
+            walk.next(alpha, a.a0, a.a1, a.split);
+        } else {
+            a.a0 = BK == 1 ? (alpha + (ub >> sh))[txs] : a_single;
+            a.a1 = a.a0; a.split = 4;
+        }
+    };
     auto accumulate = [&](const f4& gv, const int (&id)[4], const A2& a) {
         const float m[4] = {gv.x * (BK == 2 && a.split < 1 ? a.a1 : a.a0), gv.y * (BK == 2 && a.split < 2 ? a.a1 : a.a0),
                             gv.z * (BK == 2 && a.split < 3 ? a.a1 : a.a0), gv.w * (BK == 2 && a.split < 4 ? a.a1 : a.a0)};   // one fp32 multiply each, :495
@@ -316,18 +350,18 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
             B.add(id[3], m[3]);
         }
     };
-    int64_t i = tid;
-    for (; i + (int64_t)(U - 1) * nth < n4; i += (int64_t)U * nth) {     // U independent float4 in flight per lane
+    int64_t ub = bbase;
+    for (; ub + (int64_t)(U - 1) * nth + BS <= n4; ub += (int64_t)U * nth) {   // U independent float4 in flight per lane
         f4 gv[U]; int id[U][4]; A2 a[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) load4(i + (int64_t)u * nth, gv[u], id[u], a[u]);
+        for (int u = 0; u < U; ++u) load4u(ub + (int64_t)u * nth, gv[u], id[u], a[u]);
         // without this the scheduler sinks every load to its first use (to save registers) and the loop pays
         // one full memory round trip per float4
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) accumulate(gv[u], id[u], a[u]);
     }
-    for (; i < n4; i += nth) {
+    for (int64_t i = ub + tx; i < n4; i += nth) {           // the last (up to U) float4 of a lane: per-lane addresses
         f4 ga; int ia[4]; A2 sa;
         load4(i, ga, ia, sa);
         accumulate(ga, ia, sa);
@@ -371,6 +405,8 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
 // What serialises is only the table phase of a batch (U round trips of read-4-bins / add / write, ~1 k cycles); the rest --
 // HBM latency of the batch's loads (~5 k cycles), products and duplicate merging (~1.3 k) -- is private to a wave.  So G
 // single-wave groups share a [k][64] table (64 KiB at k = 256: two blocks per CU, eight waves instead of two) and pass a
+// (ds_add_f32 on the lane's column instead of read / add / write -- in order within a wave, so still deterministic under the
+// token, and no duplicate merging -- measured 345 us at k = 128 / 256 against 62 us: LDS float atomics are slow.)
 // turn token round robin through LDS: a wave issues the loads of batch i+2, waits for its turn, updates the table with
 // batch i, hands the token on, and prepares batch i+1 while the other waves take their turns.  No block barriers in the
 // loop, no atomics on the table, and deterministic: the update order is fixed (wave 0, 1, ..., G-1, batch by batch).
@@ -380,37 +416,48 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [k][64]
     __shared__ int turn;
     constexpr int C = 64;
-    const int grp = threadIdx.x >> 6;
-    float* col = lds + (threadIdx.x & 63);
-    for (int j = threadIdx.x; j < k * C; j += blockDim.x) lds[j] = 0.0f;
-    if (threadIdx.x == 0) turn = 0;
+    constexpr int BS = 64 * G;
+    const unsigned tx = threadIdx.x;
+    const int grp = tx >> 6;
+    float* col = lds + (tx & 63);
+    for (int j = tx; j < k * C; j += BS) lds[j] = 0.0f;
+    if (tx == 0) turn = 0;
     const float a_single = BK != 0 ? 0.0f : alpha[0];
     const int64_t n4 = n >> 2;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    const int64_t bbase = (int64_t)blockIdx.x * BS;         // block-uniform
+    const int64_t tid = bbase + tx;
+    const int64_t nth = (int64_t)gridDim.x * BS;
     const int64_t iters = (n4 + (int64_t)U * nth - 1) / ((int64_t)U * nth);   // the same for every wave: the token must circulate
+    // (Block-uniform base addresses and no clamps / dead-lane selects for the batches that lie inside the tensor -- 40 instead of
+    // 79 vector instructions per float4 -- measured 64.2 / 66.0 us at k = 128 / 256 against 62.2 / 64.9 with the general form
+    // below on the same box; two rings of two waves on [k][128] for k <= 128: 64.2 against 62.0.  Neither the instruction
+    // count nor the length of the token ring is what the rounds wait for; what does show is the hand-off: s_sleep 16 in the
+    // polling loop costs 10 us, s_sleep 4 gains 1.2 us over s_sleep 1 -- three waiting waves poll the LDS less often.)
     BucketWalk walk;
     if (BK == 2) walk.init(tid, nth, row, nb);
     int id[U][4];
     float sm[U][4];
-    f4 gv[U]; uint32_t pk[U]; l2 p0[U], p1[U]; float al[U], al1[U]; int spl[U];   // the raw batch in flight
+    // (TWO raw batches in flight per wave instead of one -- 20 KiB under way per wave, 229 VGPRs -- measured 66.9 / 69.9 us at
+    // k = 128 / 256 against 61.5 / 63.4: more bytes under way do not shorten the rounds.)
+    struct Raw { f4 gv[U]; uint32_t pk[U]; l2 p0[U], p1[U]; float al[U], al1[U]; int spl[U]; };
+    Raw r;                                                  // the raw batch in flight
     auto issue = [&](int64_t it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i_raw = tid + ((int64_t)it * U + u) * nth;
             const int64_t i = i_raw < n4 ? i_raw : (n4 > 0 ? n4 - 1 : 0);  // always-issued loads, clamped address
-            gv[u] = __builtin_nontemporal_load((const f4*)g + i);
+            r.gv[u] = __builtin_nontemporal_load((const f4*)g + i);
             if (IDXB == 8) {
-                p0[u] = __builtin_nontemporal_load((const l2*)idx + 2 * i);
-                p1[u] = __builtin_nontemporal_load((const l2*)idx + 2 * i + 1);
+                r.p0[u] = __builtin_nontemporal_load((const l2*)idx + 2 * i);
+                r.p1[u] = __builtin_nontemporal_load((const l2*)idx + 2 * i + 1);
             } else {
-                pk[u] = __builtin_nontemporal_load((const uint32_t*)idx + i);
+                r.pk[u] = __builtin_nontemporal_load((const uint32_t*)idx + i);
             }
             if (BK == 2) {
-                walk.next(alpha, al[u], al1[u], spl[u]);    // (issue() runs for it = 0, 1, 2, ... in this order)
+                walk.next(alpha, r.al[u], r.al1[u], r.spl[u]);
             } else {
-                al[u] = BK == 1 ? alpha[(i << 2) >> row_shift] : a_single;
-                al1[u] = al[u]; spl[u] = 4;
+                r.al[u] = BK == 1 ? alpha[(i << 2) >> row_shift] : a_single;
+                r.al1[u] = r.al[u]; r.spl[u] = 4;
             }
         }
         __builtin_amdgcn_sched_barrier(0);                  // issued here, not sunk to the first use
@@ -421,22 +468,17 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
             const int64_t i_raw = tid + ((int64_t)it * U + u) * nth;
             const bool live = i_raw < n4;
             if (IDXB == 8) {
-                id[u][0] = (int)p0[u].x; id[u][1] = (int)p0[u].y; id[u][2] = (int)p1[u].x; id[u][3] = (int)p1[u].y;
+                id[u][0] = (int)r.p0[u].x; id[u][1] = (int)r.p0[u].y; id[u][2] = (int)r.p1[u].x; id[u][3] = (int)r.p1[u].y;
             } else {
-                id[u][0] = pk[u] & 255; id[u][1] = (pk[u] >> 8) & 255; id[u][2] = (pk[u] >> 16) & 255; id[u][3] = pk[u] >> 24;
+                id[u][0] = r.pk[u] & 255; id[u][1] = (r.pk[u] >> 8) & 255; id[u][2] = (r.pk[u] >> 16) & 255; id[u][3] = r.pk[u] >> 24;
             }
             const float z = 0.0f;
-            const float m0 = live ? gv[u].x * (BK == 2 && spl[u] < 1 ? al1[u] : al[u]) : z;   // one fp32 multiply each, :495
-            const float m1 = live ? gv[u].y * (BK == 2 && spl[u] < 2 ? al1[u] : al[u]) : z;
-            const float m2 = live ? gv[u].z * (BK == 2 && spl[u] < 3 ? al1[u] : al[u]) : z;
-            const float m3 = live ? gv[u].w * (BK == 2 && spl[u] < 4 ? al1[u] : al[u]) : z;
-            const bool e01 = id[u][0] == id[u][1], e02 = id[u][0] == id[u][2], e03 = id[u][0] == id[u][3];
-            const bool e12 = id[u][1] == id[u][2], e13 = id[u][1] == id[u][3], e23 = id[u][2] == id[u][3];
-            // every element whose index matches gets the same fixed-order sum: equal addresses are written with equal values
-            sm[u][0] = ((m0 + (e01 ? m1 : z)) + (e02 ? m2 : z)) + (e03 ? m3 : z);
-            sm[u][1] = (((e01 ? m0 : z) + m1) + (e12 ? m2 : z)) + (e13 ? m3 : z);
-            sm[u][2] = (((e02 ? m0 : z) + (e12 ? m1 : z)) + m2) + (e23 ? m3 : z);
-            sm[u][3] = (((e03 ? m0 : z) + (e13 ? m1 : z)) + (e23 ? m2 : z)) + m3;
+            const float m0 = live ? r.gv[u].x * (BK == 2 && r.spl[u] < 1 ? r.al1[u] : r.al[u]) : z;   // one fp32 multiply each, :495
+            const float m1 = live ? r.gv[u].y * (BK == 2 && r.spl[u] < 2 ? r.al1[u] : r.al[u]) : z;
+            const float m2 = live ? r.gv[u].z * (BK == 2 && r.spl[u] < 3 ? r.al1[u] : r.al[u]) : z;
+            const float m3 = live ? r.gv[u].w * (BK == 2 && r.spl[u] < 4 ? r.al1[u] : r.al[u]) : z;
+            const float m[4] = {m0, m1, m2, m3};
+            merged_prefix_sums(id[u], m, sm[u]);           // the last of a lane's duplicates carries their whole sum
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -446,7 +488,7 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
             float* a0 = col + id[u][0] * C; float* a1 = col + id[u][1] * C;
             float* a2 = col + id[u][2] * C; float* a3 = col + id[u][3] * C;
             const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
-            *a0 = c0 + sm[u][0]; *a1 = c1 + sm[u][1]; *a2 = c2 + sm[u][2]; *a3 = c3 + sm[u][3];
+            *a0 = c0 + sm[u][0]; *a1 = c1 + sm[u][1]; *a2 = c2 + sm[u][2]; *a3 = c3 + sm[u][3];   // in element order (see above)
         }
     };
     if (iters > 0) {
@@ -456,11 +498,11 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
     }
     __syncthreads();                                        // table zeroed, token at wave 0
     for (int64_t it = 0; it < iters; ++it) {
-        while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != grp) __builtin_amdgcn_s_sleep(4);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         update();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's table writes are done before the token moves
-        if ((threadIdx.x & 63) == 0)
+        if ((tx & 63) == 0)
             __hip_atomic_store(&turn, grp + 1 == G ? 0 : grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (it + 1 < iters) {
             compute(it + 1);
@@ -475,7 +517,7 @@ __global__ __launch_bounds__(64 * G) void k_point_grad_turns(const float* g, con
         col[ide * C] += g[e] * (BK == 2 ? alpha[e / row] : (BK == 1 ? alpha[e >> row_shift] : a_single));
     }
     __syncthreads();
-    // 4 threads per bin, 16 columns each, rotated start (bank-conflict free), then a fixed fold
+    // 4 threads per bin, C / 4 columns each, rotated start (bank-conflict free), then a fixed fold
     constexpr int quarter = C >> 2;
     for (int t = threadIdx.x; t < ((k * 4 + 3) & ~3); t += blockDim.x) {
         const int j = t >> 2, q = t & 3;
@@ -962,7 +1004,8 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     const bool idx_ok = idx_bytes == 8 ? ((((uintptr_t)idx) & 15) == 0) : ((((uintptr_t)idx) & 3) == 0);
     // (any bucket size from 4 elements up: BK = 2 walks the buckets; only shorter buckets and misaligned tensors are left
     // to the scalar kernel)
-    const bool fast = k <= 512 && idx_ok && ((((uintptr_t)g) & kDataAlign) == 0) && (nb == 1 || row >= 4);
+    const bool walk_ok = pow2 || (nb < ((int64_t)1 << 30) && row < ((int64_t)1 << 30));
+    const bool fast = k <= 512 && idx_ok && ((((uintptr_t)g) & kDataAlign) == 0) && (nb == 1 || (row >= 4 && walk_ok));
     if (fast) {
         // k <= 4: register bins; otherwise an LDS table [k][threads] of lane-private columns
         const int threads = k <= 128 ? 256 : (k <= 256 ? 128 : 64);
@@ -998,22 +1041,16 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
                 if (tb > (int)max_rows) tb = (int)max_rows;                                                          \
                 if (tb < 1) tb = 1;                                                                                  \
                 blocks = tb;                                                                                         \
-                if constexpr (IDXB == 8) {                                                                           \
-                    auto kern = k_point_grad_turns<IDXB, BK, 4, 4>;                                                  \
-                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); \
-                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, row, nb, k, w.pg_part); \
-                } else {                                                                                             \
-                    auto kern = k_point_grad_turns<IDXB, BK, 8, 4>;                                                  \
-                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); \
-                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, row, nb, k, w.pg_part); \
-                }                                                                                                    \
+                auto kern = k_point_grad_turns<IDXB, BK, IDXB == 8 ? 4 : 8, 4>;                                      \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);   \
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), tl, st, g, idx, alpha, n, row_shift, row, nb, k, w.pg_part); \
             }                                                                                                       \
         }
         const int blocks_all = blocks_for(n, 256 * 4 * 2);
         // resident blocks per CU of the turn-token kernel; measured at k = 128: 63.4 us (2) / 65.9 us (3).  (One lane per
         // column under a table above 64 KiB -- one block per CU -- measured 66.6 / 110-121 us at k = 128 / 256 with 8 .. 32
         // float4 in flight per lane: those waves are bound by their own VALU + LDS round trips.)
-        constexpr int kTurnsBlocksPerCu = 2;
+        constexpr int kTurnsBlocksPerCu = 2;     /* two rings while two blocks of [k][128] fit a CU */
         if (idx_bytes == 8) { if (nb == 1) QD_PG_K(8, 0) else if (pow2) QD_PG_K(8, 1) else QD_PG_K(8, 2) }
         else { if (nb == 1) QD_PG_K(1, 0) else if (pow2) QD_PG_K(1, 1) else QD_PG_K(1, 2) }
 #undef QD_PG_K

@@ -492,7 +492,8 @@ def test_nonuniform_random_vs_c_oracle(k):
 
 
 @pytest.mark.parametrize('bucket,k', [(100, 4), (100, 600), (1000, 4), (1000, 600), (100, 64), (100, 100), (33, 16), (256, 600),
-                                      (None, 700), (256, 1024), (1000, 1024)])
+                                      (None, 700), (256, 1024), (1000, 1024), (100, 128), (1000, 256), (7, 16), (5, 4), (6, 200),
+                                      (3, 16), (2, 4)])
 def test_point_gradient_deterministic_and_within_1e6_on_every_path(bucket, k):
     """qd_point_grad_f32 promises a deterministic two-stage reduction on EVERY path (include/qd_hip.h).  Round 2's path for
     non-power-of-two buckets, k > 512 and misaligned index pointers used float LDS atomics, whose order is not fixed; it
@@ -530,6 +531,37 @@ def test_point_gradient_deterministic_and_within_1e6_on_every_path(bucket, k):
         for o in outs[1:]:
             assert torch.equal(o, outs[0]), (bucket, k, name, 'run-to-run difference')
         errlog.check_sum('K6 point gradient, every path (bucket %s, k = %d)' % (bucket, k), host(outs[0]), want, absum,
+                         (bucket, k, name), n_terms=n)
+
+
+@pytest.mark.parametrize('bucket,k', [(100, 4), (7, 16), (1000, 64), (4097, 128), (100, 256), (33, 4), (256, 16)])
+def test_point_gradient_long_streams_at_any_bucket_size(bucket, k):
+    """The float4 kernels of K6 walk the buckets of a lane's stream incrementally at non-power-of-two bucket sizes (one
+    division per lane, then (bucket, offset) advanced per load; qd_reductions.hip BucketWalk).  8 Mi + 5 elements give every
+    lane 16 and more steps of that walk, with the padded last bucket and a scalar tail; the alphas differ by orders of
+    magnitude between neighbouring buckets so that a float4 given the wrong bucket cannot hide inside the tolerance
+    (ref: quant_functions.py:493-503)."""
+    lib = _lib.load()
+    rng = np.random.RandomState(k * 11 + bucket)
+    n = (1 << 23) + 5
+    g = rng.randn(n).astype(np.float32)
+    idx = rng.randint(0, k, size=n).astype(np.uint8 if k <= 256 else np.int64)
+    nb = (n + bucket - 1) // bucket
+    alpha = (10.0 ** rng.randint(-3, 4, size=nb)).astype(np.float32)
+    want, absum = oc.point_grad(g, idx.astype(np.int64), alpha, bucket, k)
+    gd, ad = dev(g), dev(alpha)
+    ws = torch.empty(lib.qd_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for name, it, ib in (('uint8', dev(idx), 1), ('int64', dev(idx.astype(np.int64)), 8)):
+        outs = []
+        for rep in range(3):
+            out = torch.full((k,), float('nan'), device=DEV)
+            _lib.check(lib.qd_point_grad_f32(gd.data_ptr(), it.data_ptr(), ib, ad.data_ptr(), n, bucket, k, out.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), st))
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), (bucket, k, name, 'run-to-run difference')
+        errlog.check_sum('K6 point gradient, long streams (bucket %d, k = %d)' % (bucket, k), host(outs[0]), want, absum,
                          (bucket, k, name), n_terms=n)
 
 

@@ -11,6 +11,7 @@
 #   ragged     tools/ragged_probe.py
 #   api        tools/profile_api_overhead.py
 #   soak       property tests with QD_SOAK=10
+#   sqk6       SQ counters of the point-gradient kernels (k = 16 / 64 / 128 / 256; tools/sq_probe_k6.py)
 #   sq         SQ counters (VALU / LDS instructions, LDS bank conflicts) of the nearest-point calls, before / after
 #   side       tools/side_output_probe.py (calls with index / level side outputs at every bucket-size family; SIDE_ARGS)
 #   spread     tools/distill_spread_probe.py: repetition-to-repetition spread of the configs[1] step, with a kernel trace
@@ -51,6 +52,11 @@ for step in "$@"; do
                unset QD_LIB
              done
              python tools/sq_summarize_r3.py > gpurun_out/sq_counters.txt 2>&1; cat gpurun_out/sq_counters.txt ;;
+    sqk6)    # SQ counters of the point-gradient kernels (tools/sq_probe_k6.py)
+             rm -rf gpurun_out/sq_k6
+             (cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $R/gpurun_out/sq_k6 -o sq -- python $R/tools/sq_probe_k6.py > /dev/null 2> $R/gpurun_out/sq_k6.err); echo "sq k6 rc=$?"
+             python tools/sq_probe_k6.py --summarize > gpurun_out/sq_counters_k6.txt 2>&1; cat gpurun_out/sq_counters_k6.txt
+             find gpurun_out/sq_k6 -name '*.csv' -size +8M -delete ;;
     side)    timeout 900 python tools/side_output_probe.py $SIDE_ARGS 2>&1 | grep -v amdgpu.ids > gpurun_out/side_output.txt; cat gpurun_out/side_output.txt ;;
     spread)  timeout 600 python tools/distill_spread_probe.py --sleep 0.5 2>&1 | grep -v amdgpu.ids > gpurun_out/distill_spread.txt; head -20 gpurun_out/distill_spread.txt
              rm -rf gpurun_out/spread_trace
