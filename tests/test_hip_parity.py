@@ -774,6 +774,51 @@ def test_beyond_int32_elements():
     assert abs(float(gsum.double().sum()) - want) <= 1e-5 * want
 
 
+def test_beyond_int32_elements_at_a_bucket_size_that_is_not_a_power_of_two():
+    """Maximum sizes, second half: more than 2^31 elements at bucket 100 -- the stream kernels of the pre-processed forward
+    (K5) and of inv_scale_down (K3) take their 64-bit division branch there, the chunk kernel of scale_down (K2) and the
+    bucket walk of the point gradient (K6) index past 2^31.  Windows around the 2^31-st element and at the ragged tail
+    against the oracle; the point gradient through sum_j grad_j = sum_i alpha_bucket(i) for g = 1."""
+    bucket = 100
+    n = (1 << 31) + bucket * 7 + 13
+    free, _ = torch.cuda.mem_get_info()
+    if free < 5 * n * 4 + (4 << 30):
+        pytest.skip('not enough free HBM for the 2^31-element test')
+    x = torch.empty(n, device=DEV)
+    piece = 1 << 28
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for lo in range(0, n, piece):
+        x[lo:lo + piece].normal_(generator=g)
+    pts = torch.tensor([0.0, 0.3, 0.55, 1.0], device=DEV)
+    fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=x)
+    qn = fn.forward(None, pts)
+    idx = fn.savedForBackward.raw_indices()
+    assert idx.dtype == torch.uint8 and idx.numel() == n and qn.numel() == n
+    first_after = ((1 << 31) // bucket) * bucket                 # the bucket that straddles element 2^31
+    windows = (0, first_after - bucket * 3, n - (n % bucket) - bucket * 4)
+    for lo in windows:
+        hi = min(n, lo + bucket * 8)
+        r = oc.nonuniform_quantize(host(x[lo:hi]), host(pts), bucket, 'midpoint')
+        assert np.array_equal(host(qn[lo:hi]), r['q']), lo
+        assert np.array_equal(host(idx[lo:hi]).astype(np.int64), r['idx']), lo
+    del qn
+    # K2 -> K3 on the same tensor: inv_scale_down(scale_down(x)) against the oracle's round trip on the windows
+    sf = quantization.ScalingFunction('linear', False, False, bucket)
+    u = sf.scale_down(x)
+    back = sf.inv_scale_down(u)
+    for lo in windows:
+        hi = min(n, lo + bucket * 8)
+        ro = onp.scale_down(host(x[lo:hi]), bucket)
+        assert np.array_equal(host(u.view(-1)[lo:hi]), ro['u'].reshape(-1)[:hi - lo]), lo
+        want = onp.inv_scale_down(ro['u'], ro['alpha'], ro['beta'], 0.0, hi - lo, (hi - lo,))
+        assert np.array_equal(host(back.view(-1)[lo:hi]), want), lo
+    del u, back
+    gsum = fn.backward(torch.ones_like(x))[1]
+    al = fn.scaling_function.alpha.view(-1).double()
+    want = float(al[:-1].sum() * bucket + al[-1] * (n % bucket))
+    assert abs(float(gsum.double().sum()) - want) <= 1e-5 * want
+
+
 # ------------------------------------------------------------------------------ packed codec + histograms
 @pytest.mark.parametrize('s,bits', [(2, 1), (4, 2), (3, 2), (16, 4), (9, 4), (256, 8), (16, 8)])
 def test_pack_unpack_roundtrip(s, bits):
