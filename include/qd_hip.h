@@ -251,9 +251,11 @@ int qd_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int m, f
 /* ---- self test of the bucket-invariant division (csrc/qd_selftest.hip).  The quantize kernels replace the IEEE division
  * u = (x - beta) / alpha of quantization/quant_functions.py:106-107 by y = RN(1/alpha) once per bucket and two FMAs per
  * element (qd_common.h: div_alpha<true>), which must give the correctly rounded quotient bit for bit wherever it is used:
- * alpha in [2^-60, 2^100], n = 0 or n >= 2^-100.  This entry point generates `npairs` adversarial (n, alpha) pairs of
- * `family` 0 .. 4 on the device (0: the quantizer's own domain, 1: wide exponents, 2: all-ones / near-power-of-two
- * significands, 3: near-exact quotients around level and half-level values, 4: the edges of the stated ranges), evaluates
+ * alpha in [2^-60, 2^100], n = 0 or n >= 2^-100 -- and, where the quotient itself is returned (qd_scale_down_f32), n >=
+ * alpha 2^-120 as well (a normal quotient).  This entry point generates `npairs` adversarial (n, alpha) pairs of
+ * `family` 0 .. 5 on the device (0: the quantizer's own domain, 1: wide exponents, 2: all-ones / near-power-of-two
+ * significands, 3: near-exact quotients around level and half-level values, 4: the edges of the stated ranges, 5: small
+ * normal quotients 2^-120 .. 2^-50), evaluates
  * the shortcut with the very function the kernels inline and compares it with n / alpha.
  * result (device, 4 x uint64): pairs tested, mismatches, (n bits << 32 | alpha bits) of one mismatch, pairs skipped
  * as outside the domain.  tools/div_invariant_check.py, tests/test_hip_parity.py. */

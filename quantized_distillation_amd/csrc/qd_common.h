@@ -208,8 +208,10 @@ __device__ __forceinline__ void alpha_beta(float mn, float mx, float& a, float& 
 // normal y; both hold for alpha in [2^-60, 2^100] and n = 0 or n >= 2^-100 (checked against true division on 5 * 10^9
 // adversarial pairs incl. all-ones significands: 0 mismatches; outside those ranges mismatches do occur).  A numerator
 // below 2^-100 with alpha >= 2^-60 gives u < 2^-40, whose level is 0 whatever its last bit is -- so the form is used
-// where only the LEVEL of u is consumed (quantize-dequantize, deterministic or stochastic), never where u itself is
-// returned (scale_down) or compared with points.  Buckets outside the range (incl. inf / NaN alpha) take the IEEE path.
+// where only the LEVEL of u is consumed (quantize-dequantize, deterministic or stochastic) without looking at the
+// numerators; scale_down, which returns u itself, uses it in the buckets whose nonzero numerators are all at least
+// max(2^-100, alpha 2^-120) -- a NORMAL quotient; a denormal one can differ in its last bit (qd_transform.h scale_fast_ok) --
+// and never where u is compared with points.  Buckets outside the range (incl. inf / NaN alpha) take the IEEE path.
 __device__ __forceinline__ bool fastdiv_ok(float a) { return a >= 0x1p-60f && a <= 0x1p100f; }   // false for NaN
 template <bool FAST>
 __device__ __forceinline__ float div_alpha(float n, float a, float y) {

@@ -10,6 +10,8 @@
 //
 // Domain of the claim (qd_common.h): alpha in [2^-60, 2^100] (fastdiv_ok), n = 0 or 2^-100 <= n, n / alpha finite.  In
 // the kernels n = x - min(bucket) and alpha = max(bucket) - min(bucket), so 0 <= n <= alpha always (rounding is monotone).
+// Where only the LEVEL of the quotient is consumed (quantize-dequantize) that is all; where the quotient itself is returned
+// (scale_down) the numerator must also be 0 or >= alpha 2^-120, i.e. the quotient normal (family 5).
 
 #include "qd_common.h"
 #include "../../include/qd_hip.h"
@@ -95,6 +97,16 @@ __global__ __launch_bounds__(256) void k_selftest_div(uint64_t seed, int64_t npa
             const int d = (int)((h2 >> 44) % 5u) - 2;
             n = __uint_as_float(__float_as_uint(p) + (uint32_t)d);
             if (!(n >= 0.0f)) n = 0.0f;
+        } else if (family == 5) {
+            // small quotients: scale_down returns u itself, so the form must hold down to the smallest NORMAL quotients --
+            // numerators from 2^-100 up, quotient exponents -120 .. -50 (denormal quotients are outside the claim: there the
+            // last bit can differ, and the kernels' numerator threshold max(2^-100, alpha 2^-120) keeps them out)
+            const int ea = (int)(h0 % 151u) - 50;                        // exponent of alpha: -50 .. 100
+            a = from_parts(0, ea, (h0 & (1ull << 40)) ? nasty_mantissa(h1) : (uint32_t)(h1 >> 20));
+            const int lo = ea - 120 > -100 ? ea - 120 : -100, hi = ea - 50;
+            const int en = lo + (int)((h2 >> 8) % (uint32_t)(hi - lo + 1));
+            n = from_parts(0, en, (h2 & 1) ? nasty_mantissa(h2 >> 4) : (uint32_t)(h2 >> 36));
+            if (n < a * 0x1p-120f) n = 0.0f;
         } else {
             // the edges of the stated ranges: alpha at 2^-60 / 2^100 (+- an ulp inside), n at 2^-100 and at alpha
             const uint32_t pick = (uint32_t)(h0 & 3u);
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256) void k_selftest_div(uint64_t seed, int64_t npa
 
 extern "C" int qd_selftest_div_invariant(uint64_t seed, int64_t npairs, int family, unsigned long long* result,
                                          void* stream) {
-    if (npairs < 0 || family < 0 || family > 4 || !result) return QD_ERR_INVALID_ARGUMENT;
+    if (npairs < 0 || family < 0 || family > 5 || !result) return QD_ERR_INVALID_ARGUMENT;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(result, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return (int)hipGetLastError();
     if (npairs == 0) return 0;

@@ -266,6 +266,19 @@ __device__ __forceinline__ int assign_point(const PointStore& T, int k, int mode
     return i;
 }
 
+// scale_down RETURNS u, so the bucket-invariant division form (qd_common.h) may replace the IEEE division only in a bucket
+// whose alpha is in the proven range AND whose numerators v - beta are all 0 or at least max(2^-100, alpha 2^-120): below
+// 2^-100 the remainder underflows, and a DENORMAL quotient can differ in its last bit (exact-arithmetic restatement,
+// tools/div_invariant_check.py: 3 of 3518 such pairs; 0 of 33824 with small normal quotients; family 5 of the device self
+// test).  One unsigned minimum per element decides it: bits(n) - 1 wraps 0 to the top, and n >= 0 (beta is the bucket's
+// minimum; a NaN anywhere makes alpha NaN, which fastdiv_ok refuses).  Almost every bucket of real data passes; one that
+// does not takes the IEEE form as before.
+__device__ __forceinline__ unsigned scale_numerator_key(float v, float b) { return __float_as_uint(v - b) - 1u; }
+__device__ __forceinline__ bool scale_fast_ok(float a, unsigned min_key) {
+    const float thr = fmaxf(0x1p-100f, a * 0x1p-120f);
+    return fastdiv_ok(a) && min_key >= __float_as_uint(thr) - 1u;
+}
+
 // ---- per-element transform shared by every bucket kernel -----------------------------------
 // v: prepared value (mean subtracted, clamped) -- or u itself when prescaled.
 // e: global element index (for the side outputs and the random stream).
@@ -277,7 +290,7 @@ __device__ __forceinline__ float transform(const KParams& p, const PointTable* T
                             : qdq<FAST>(v, a, b, p.sm1, mean, side, y);
     } else if (MODE == MODE_SCALE) {
         float u = v - b;
-        u = u / a;
+        u = div_alpha<FAST>(u, a, y);                // FAST only where the caller has checked the bucket (scale_fast_ok)
         return u;
     } else {
         float u = v;
@@ -601,7 +614,13 @@ __device__ __forceinline__ void vec_apply(const KParams& p, const PointTable* T,
         } else {
             r = transform_f4<MODE, FAST>(p, T, v[j], a, b, pp.mean, rnd, side, y);
         }
-        __builtin_nontemporal_store(r, dst + j * LPB);
+        // MODE_SCALE: the whole-tile and partial-tile copies of this loop are merged by the compiler, and the merged store loses
+        // its !nontemporal flag (ISA: plain global_store_dwordx4; 92 us against the 83 us of the same traffic in MODE_QDQ) --
+        // an instruction written out cannot lose it.  (The s_nop is the wait state the hardware needs between a store of more than
+        // 8 bytes and a VALU write of its data registers; the compiler's hazard recogniser does not look inside an asm block:
+        // without it the [257]-element golden case stored a register the next instruction had already overwritten.)
+        if (MODE == MODE_SCALE) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst + j * LPB), "v"(r) : "memory");
+        else __builtin_nontemporal_store(r, dst + j * LPB);
         store_side4_row<MODE>(p, e, side);
     }
 }
@@ -634,7 +653,16 @@ __device__ __forceinline__ void vec_bucket(const KParams& p, const PointTable* T
     // (variant, division form) and chosen ONCE per bucket: with the flags tested inside the loop the compiler no longer
     // unswitched it and the kernel executed 37.9 M instead of 33.9 M VALU wave-instructions (profiles/r02_sq_counters.txt).
     const bool fast = MODE == MODE_QDQ && !__any(!fastdiv_ok(a));
-    if (MODE != MODE_QDQ) vec_apply<MODE, LPB, V, 2, false>(p, T, pp, fl, v, e0, a, b);
+    if (MODE == MODE_SCALE) {
+        unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            key = min(key, min(scale_numerator_key(v[j].x, b), scale_numerator_key(v[j].y, b)));
+            key = min(key, min(scale_numerator_key(v[j].z, b), scale_numerator_key(v[j].w, b)));
+        }
+        if (!__any(!scale_fast_ok(a, key))) vec_apply<MODE, LPB, V, 2, true>(p, T, pp, fl, v, e0, a, b);
+        else vec_apply<MODE, LPB, V, 2, false>(p, T, pp, fl, v, e0, a, b);
+    } else if (MODE != MODE_QDQ) vec_apply<MODE, LPB, V, 2, false>(p, T, pp, fl, v, e0, a, b);
     else if (fast) {
         if (fl.use_tab) vec_apply<MODE, LPB, V, 0, true>(p, T, pp, fl, v, e0, a, b);
         else if (fl.use_tab_s) vec_apply<MODE, LPB, V, 1, true>(p, T, pp, fl, v, e0, a, b);

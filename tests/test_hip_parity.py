@@ -1203,9 +1203,9 @@ def test_single_bucket_fused_many_launches_in_flight(fused_mode):
 
 # ------------------------------------------------------------------------------ bucket-invariant division (round 2)
 def test_division_by_bucket_invariant_alpha():
-    """Device-side proof slice: 10^8 adversarial (n, alpha) pairs (five families of 2 * 10^7: the quantizer's own domain, wide
-    exponents, all-ones / near-power-of-two significands, near-exact quotients around level values, the edges of the
-    stated ranges) through the very inline function the kernels use (qd_selftest_div_invariant, csrc/qd_selftest.hip)
+    """Device-side proof slice: 1.2 * 10^8 adversarial (n, alpha) pairs (six families of 2 * 10^7: the quantizer's own domain,
+    wide exponents, all-ones / near-power-of-two significands, near-exact quotients around level values, the edges of the
+    stated ranges, small normal quotients down to 2^-120 -- what scale_down adds) through the very inline function the kernels use (qd_selftest_div_invariant, csrc/qd_selftest.hip)
     against the IEEE quotient: 0 mismatches required.  tools/div_invariant_check.py --pairs 1e9 is the long run
     (profiles/r03_div_invariant.txt).  ref: quant_functions.py:106-107."""
     import sys
@@ -1255,6 +1255,48 @@ def test_quantize_bit_exact_at_extreme_scales(bucket):
         rand[:n] = onp.philox4x32_7_uniform(seed, n)
         ws = onp.uniform_quantize_stochastic(x, 16, rand, bucket)
         assert np.array_equal(host(qs), ws['q'], equal_nan=True), (bucket, ci, 'stochastic')
+
+
+@pytest.mark.parametrize('bucket', [256, 64, 1024, 100, 33])
+def test_scale_down_bit_exact_at_extreme_scales(bucket):
+    """scale_down RETURNS u = (x - beta) / alpha, so where its vector kernel divides through y = RN(1/alpha) and two FMAs
+    (buckets whose alpha is in [2^-60, 2^100] and whose nonzero numerators are all >= max(2^-100, alpha 2^-120): a normal
+    quotient; qd_transform.h scale_fast_ok) every BIT of u must equal the IEEE quotient of quant_functions.py:106-107.
+    Buckets on both sides of each condition: numerators below 2^-100, denormal quotients (where the shortcut can differ in
+    the last bit and must not be taken), quotients at the 2^-120 threshold, tiny / huge / mixed scales, zeros next to
+    denormals, constant buckets -- u, alpha, beta compared as bit patterns with the numpy oracle."""
+    rng = np.random.RandomState(bucket + 17)
+    n = 64 * 1024 + 5
+    base = rng.randn(n).astype(np.float32)
+    scales = [1.0, 1e-3, 2.0 ** -58, 2.0 ** -61, 1e-30, 1e-37, 1e-39, 2.0 ** 99, 2.0 ** 101, 1e30]
+    cases = [(base * np.float32(sc)).astype(np.float32) for sc in scales]
+    per = np.repeat(np.array(scales * 400, dtype=np.float64)[: (n + 255) // 256], 256)[:n]
+    cases.append((base.astype(np.float64) * per).astype(np.float32))       # a different scale every 256 elements
+    # one large element per bucket-ish stretch over tiny ones: numerators 2^-130 .. 2^-80 under alpha = 2^e, e = -10 .. 60
+    # -> quotients from deep in the denormal range up to small normal ones, on both sides of both thresholds
+    tiny = (np.abs(base).astype(np.float64) + 0.5) * (2.0 ** rng.randint(-130, -80, size=n))
+    big_at = rng.rand(n) < 1.0 / 40
+    tiny[big_at] = 2.0 ** rng.randint(-10, 60, size=int(big_at.sum()))
+    tiny[rng.rand(n) < 0.2] = 0.0
+    cases.append(tiny.astype(np.float32))
+    exact = np.zeros(n, np.float64)                                          # quotients exactly AT the 2^-120 threshold
+    exact[:] = 2.0 ** -100 * rng.randint(0, 5, size=n)
+    exact[::37] = 2.0 ** 20
+    cases.append(exact.astype(np.float32))
+    cases.append(np.where(rng.rand(n) < 0.7, 0.0, base * 1e-41).astype(np.float32))   # zeros next to denormals
+    cases.append((np.abs(base) * np.float32(1e-36) + np.float32(1.0)).astype(np.float32))   # alpha < 1e-10 -> 1
+    for ci, x in enumerate(cases):
+        want = onp.scale_down(x, bucket)
+        sf = quantization.ScalingFunction('linear', False, False, bucket)
+        u = host(sf.scale_down(dev(x))).reshape(-1)
+        wu = want['u'].reshape(-1)
+        assert u.size == wu.size
+        nan = np.isnan(wu)
+        assert np.array_equal(np.isnan(u), nan), (bucket, ci)
+        diff = (u.view(np.uint32) != wu.view(np.uint32)) & ~nan
+        assert not diff.any(), (bucket, ci, int(diff.sum()), u[diff][:4], wu[diff][:4])
+        assert np.array_equal(host(sf.alpha).reshape(-1).view(np.uint32), want['alpha'].reshape(-1).view(np.uint32)), (bucket, ci)
+        assert np.array_equal(host(sf.beta).reshape(-1).view(np.uint32), want['beta'].reshape(-1).view(np.uint32)), (bucket, ci)
 
 
 def test_multi_tensor_bit_exact_at_extreme_scales():

@@ -194,3 +194,9 @@ def test_bucket_invariant_division_in_exact_arithmetic():
     bad, outside_bad = dic.run_host(30000, seed=3, verbose=False)
     assert bad == 0
     assert outside_bad > 0
+    # scale_down returns the quotient itself: exact while the quotient is normal (or rounds to zero), not always when it is
+    # denormal -- the kernels' numerator threshold max(2^-100, alpha 2^-120) keeps those buckets on the IEEE division
+    st = dic.run_host_small_quotients(20000, seed=5, verbose=False)
+    assert st['normal'][0] > 10000 and st['normal'][1] == 0
+    assert st['zero'][1] == 0
+    assert st['denormal'][0] > 500

@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 
 FAMILIES = ['quantizer domain (n = x - min, alpha = max - min)', 'wide exponents, random significands',
             'all-ones / near-power-of-two significands', 'near-exact quotients (level and half-level values +- 2 ulp)',
-            'edges of the stated ranges (alpha = 2^-60 / 2^100, n = 2^-100 / alpha)']
+            'edges of the stated ranges (alpha = 2^-60 / 2^100, n = 2^-100 / alpha)',
+            'small normal quotients 2^-120 .. 2^-50, n >= 2^-100 (scale_down returns u itself)']
 
 
 # ---------------------------------------------------------------------------------------------- exact host restatement
@@ -117,6 +118,30 @@ def run_host(count, seed=0, verbose=True):
     return bad, out_bad
 
 
+def run_host_small_quotients(count, seed=0, verbose=True):
+    """Pairs with alpha in [2^-50, 2^100], n >= 2^-100 and quotient exponents down to -200.  Returns the mismatches among
+    (normal quotients, denormal quotients, quotients that round to zero) and how many of each were tried: the shortcut is
+    exact for the first and the last class and NOT always for the denormal one, which is why scale_down -- the only caller
+    that returns the quotient itself -- refuses buckets with a numerator below alpha 2^-120."""
+    rng = np.random.RandomState(seed)
+    nasty = np.array([0x7FFFFF, 0x7FFFFE, 0, 1, 2, 0x400000, 0x3FFFFF, 0x555555, 0x2AAAAA, 0x7FF000], dtype=np.uint32)
+
+    def mant():
+        return int(nasty[rng.randint(len(nasty))]) if rng.rand() < 0.5 else int(rng.randint(0, 1 << 23))
+    stats = {'normal': [0, 0], 'denormal': [0, 0], 'zero': [0, 0]}
+    for _ in range(count):
+        ea = int(rng.randint(-50, 101))
+        en = int(rng.randint(-100, ea - 49))                       # quotient exponent in [-100 - ea, -50]
+        n, a = f32_fraction(((en + 127) << 23) | mant()), f32_fraction(((ea + 127) << 23) | mant())
+        u, want = div_invariant_exact(n, a)
+        cls = 'zero' if want == 0 else ('denormal' if want < Fraction(2) ** -126 else 'normal')
+        stats[cls][0] += 1
+        stats[cls][1] += (u != want)
+    if verbose:
+        print('host, small quotients (n >= 2^-100): ' + ', '.join('%s %d tried / %d differ' % (k, v[0], v[1]) for k, v in stats.items()))
+    return stats
+
+
 # ------------------------------------------------------------------------------------------------------- device driver
 def run_device(pairs, seed=1, chunk=1 << 28, verbose=True):
     import torch
@@ -158,6 +183,8 @@ def main():
     if a.cpu:
         bad, _ = run_host(a.cpu, a.seed)
         rc |= 1 if bad else 0
+        st = run_host_small_quotients(a.cpu, a.seed)
+        rc |= 1 if (st['normal'][1] or st['zero'][1]) else 0
     if a.pairs:
         import torch
         print('device: %s, torch %s, hip %s' % (torch.cuda.get_device_name(0), torch.__version__, torch.version.hip))
