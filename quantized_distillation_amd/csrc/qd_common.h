@@ -25,6 +25,16 @@ template <typename T> __device__ __forceinline__ T ldg_nt(const T* p) {
 template <typename T> __device__ __forceinline__ void stg_nt(const T& v, T* p) {
     __builtin_nontemporal_store(v, (QD_AS_GLOBAL T*)p);
 }
+
+// A non-temporal 16-byte store the optimiser cannot strip of its hint.  When the compiler merges two copies of a loop (the
+// whole-tile and the partial-tile branch of a kernel) the merged store can lose !nontemporal -- the ISA then shows a plain
+// global_store_dwordx4 and a write-once output starts competing for the caches (scale_down at bucket 256: 92 us against
+// 85 us).  tests/test_abi.py checks the shipped code objects for that.  The s_nop is the wait state the hardware needs
+// between a store of more than 8 bytes and a VALU write of its data registers: the hazard recogniser does not look inside
+// an asm block (without it a golden case stored a register the next instruction had already overwritten).
+__device__ __forceinline__ void store_nt_pinned(f4* p, const f4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
 template <typename T> __device__ __forceinline__ T ldg(const T* p) { return *(const QD_AS_GLOBAL T*)p; }
 template <typename T> __device__ __forceinline__ void stg(const T& v, T* p) { *(QD_AS_GLOBAL T*)p = v; }
 // wave index within the grid as a scalar (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)

@@ -614,12 +614,9 @@ __device__ __forceinline__ void vec_apply(const KParams& p, const PointTable* T,
         } else {
             r = transform_f4<MODE, FAST>(p, T, v[j], a, b, pp.mean, rnd, side, y);
         }
-        // MODE_SCALE: the whole-tile and partial-tile copies of this loop are merged by the compiler, and the merged store loses
-        // its !nontemporal flag (ISA: plain global_store_dwordx4; 92 us against the 83 us of the same traffic in MODE_QDQ) --
-        // an instruction written out cannot lose it.  (The s_nop is the wait state the hardware needs between a store of more than
-        // 8 bytes and a VALU write of its data registers; the compiler's hazard recogniser does not look inside an asm block:
-        // without it the [257]-element golden case stored a register the next instruction had already overwritten.)
-        if (MODE == MODE_SCALE) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(dst + j * LPB), "v"(r) : "memory");
+        // MODE_SCALE: the whole-tile and partial-tile copies of this loop are merged by the compiler, and the merged store
+        // loses its !nontemporal flag (qd_common.h store_nt_pinned)
+        if (MODE == MODE_SCALE) store_nt_pinned(dst + j * LPB, r);
         else __builtin_nontemporal_store(r, dst + j * LPB);
         store_side4_row<MODE>(p, e, side);
     }

@@ -126,6 +126,34 @@ def test_no_kernel_uses_scratch_memory(lib):
     assert all(k['vgpr_count'] <= 512 for k in ks)
 
 
+def test_write_once_outputs_keep_their_non_temporal_hint(lib):
+    """The streaming kernels store their write-once outputs with the non-temporal hint (global_store_dwordx4 ... nt).  The
+    optimiser can lose it: when it merges two copies of a loop the merged store drops !nontemporal, and the kernel then
+    runs with plain stores (scale_down shipped like that through round 3: 92 us against 85 us at bucket 256).  Read from
+    the disassembly of the shipped code objects: every 16-byte global store of every kernel carries `nt`, except the int64
+    point indices of the nearest-point kernels (plain on purpose: 175.8 us against 180.0 us with the hint, qd_transform.h
+    store_side4_row) and the two in-place epilogues that rewrite only the float4s they change."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import kernel_meta
+    ws = kernel_meta.wide_stores(_lib.LIB_PATH)
+    dm = kernel_meta.demangle(list(ws))
+    assert len(ws) >= 60, 'expected the streaming kernels, found %d with 16-byte stores' % len(ws)
+    bad = []
+    for sym, (total, nt) in ws.items():
+        name = dm[sym].replace('(anonymous namespace)::', '')
+        nearest = re.search(r'k_(bucket_\w+|single_\w+)<2,', name) or re.search(r'k_single_apply<2>', name) or 'k_nearest_prescaled_stream' in name
+        in_place = name.startswith('k_clamp(') or name.startswith('k_truncated_ste(')
+        if in_place:
+            continue
+        if nearest:
+            if nt * 5 < total or nt == 0:                   # the q stores (one in five with int64 indices) keep the hint
+                bad.append((name, total, nt))
+        elif nt != total:
+            bad.append((name, total, nt))
+    assert not bad, bad
+
+
 def test_no_environment_knobs_in_the_product(lib):
     """One code path per configuration: the product library reads no environment variable (round 2 shipped nine QD_*
     A/B knobs that switched between alternative kernel implementations at run time).  libqd_hip.so neither imports

@@ -83,6 +83,28 @@ def kernels(so_path):
     return res
 
 
+def wide_stores(so_path):
+    """{kernel symbol: (16-byte global stores, how many of them carry the `nt` hint)} from the disassembly of the shipped code
+    objects (llvm-objdump).  The write-once outputs of the streaming kernels are stored non-temporally; a hint lost on the
+    way through the optimiser (merged loop copies drop !nontemporal) shows up here as a plain global_store_dwordx4."""
+    res = {}
+    for img in code_objects(so_path):
+        with tempfile.NamedTemporaryFile(suffix='.co') as f:
+            f.write(img)
+            f.flush()
+            txt = subprocess.check_output([_tool('llvm-objdump'), '-d', '--mcpu=gfx950', f.name]).decode()
+        name = None
+        for line in txt.splitlines():
+            m = re.match(r'^[0-9a-f]+ <([^>]+)>:', line)
+            if m:
+                name = m.group(1)
+                continue
+            if name and 'global_store_dwordx4' in line:
+                tot, nt = res.get(name, (0, 0))
+                res[name] = (tot + 1, nt + (1 if re.search(r'\bnt\b', line) else 0))
+    return res
+
+
 def demangle(names):
     try:
         out = subprocess.check_output([shutil.which('c++filt') or _tool('llvm-cxxfilt')] + list(names)).decode().splitlines()
