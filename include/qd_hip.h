@@ -120,7 +120,9 @@ int qd_bucket_argminmax_f32(const float* x, int64_t n, int64_t bucket, const flo
  * strictly-closer-lower rule, :267-273) or QD_ASSIGN_MIDPOINT (#{midpoints <= u}, the
  * SearchSorted.query formulation, :531-573).
  * q: [n] = points[idx]*alpha + beta (+mean).  idx: optional, idx_bytes 8 (int64, what the
- * reference API returns) or 1 (uint8, k <= 256). */
+ * reference API returns) or 1 (uint8, k <= 256).
+ * Indices only (what SearchSorted.query returns, :531-563): prescaled != 0 with q == NULL and idx given -- n >= 4,
+ * buckets of at least 4 elements (or bucket == 0), x 16-byte aligned; QD_ERR_INVALID_ARGUMENT otherwise. */
 int qd_nearest_point_f32(const float* x, int prescaled, const float* points, int k, int assign_mode, float* q,
                          void* idx, int idx_bytes, int64_t n, int64_t bucket, float* alpha, float* beta,
                          const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,

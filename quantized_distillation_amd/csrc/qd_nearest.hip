@@ -90,11 +90,11 @@ __global__ __launch_bounds__(256) void k_nearest_prescaled_stream(KParams p) {
             const bool row_in = !group_any<16>(!live);                       // the 16 float4s of the DPP row are all in range
             if (row_in) {
                 const f4 rr = {o[0], o[1], o[2], o[3]};
-                __builtin_nontemporal_store(rr, dst + ii);
+                if (dst) __builtin_nontemporal_store(rr, dst + ii);          // (q == NULL: indices only, SearchSorted.query)
                 store_side4_row<MODE_NEAREST>(p, e, side);
             } else if (live) {
                 const f4 rr = {o[0], o[1], o[2], o[3]};
-                __builtin_nontemporal_store(rr, dst + ii);
+                if (dst) __builtin_nontemporal_store(rr, dst + ii);
                 store_side4<MODE_NEAREST>(p, e, side);
             }
         }
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void k_nearest_prescaled_stream(KParams p) {
         for (int64_t e = n4 << 2; e < p.n; ++e) {
             const int64_t bb = e / row < last_b ? e / row : last_b;
             float side = 0.0f;
-            p.out[e] = transform<MODE_NEAREST>(p, T, p.x[e], p.alpha[bb], p.beta[bb], mean, 0.0f, side);
+            const float y = transform<MODE_NEAREST>(p, T, p.x[e], p.alpha[bb], p.beta[bb], mean, 0.0f, side);
+            if (p.out) p.out[e] = y;
             store_side1<MODE_NEAREST>(p, e, side);
         }
     }
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(256) void k_nearest_prescaled_stream(KParams p) {
 bool launch_prescaled_stream(KParams& p, int64_t bucket, hipStream_t st, int& rc) {
     if (!p.prescaled || p.n < 4) return false;
     geometry(p.n, bucket, p.nb, p.row);
-    if (p.nb <= 1 || p.row < 4) return false;
+    if (p.row < 4) return false;
+    if (p.nb <= 1 && p.out) return false;          // one bucket: the single-bucket apply kernel already is a plain stream
     if (((((uintptr_t)p.x) | ((uintptr_t)p.out)) & kDataAlign) != 0) return false;
     if (p.idx && (p.idx_bytes == 8 ? (((uintptr_t)p.idx) & 15) != 0 : (((uintptr_t)p.idx) & 3) != 0)) return false;
     const size_t tb = point_table_bytes(p.k, p.fine);
@@ -135,8 +137,8 @@ int qd_nearest_point_f32(const float* x, int prescaled, const float* points, int
                          void* idx, int idx_bytes, int64_t n, int64_t bucket, float* alpha, float* beta,
                          const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,
                          void* stream) {
-    if (n < 0 || bucket < 0 || k < 1 || k > kMaxPoints || !points || (n > 0 && (!x || !q)))
-        return QD_ERR_INVALID_ARGUMENT;
+    if (n < 0 || bucket < 0 || k < 1 || k > kMaxPoints || !points || (n > 0 && !x)) return QD_ERR_INVALID_ARGUMENT;
+    if (n > 0 && !q && !(prescaled && idx)) return QD_ERR_INVALID_ARGUMENT;   // indices only: the pre-scaled stream kernel
     if (idx && idx_bytes != 8 && idx_bytes != 1) return QD_ERR_INVALID_ARGUMENT;
     if (idx && idx_bytes == 1 && k > 256) return QD_ERR_INVALID_ARGUMENT;
     if (assign_mode != QD_ASSIGN_DISTANCE && assign_mode != QD_ASSIGN_MIDPOINT) return QD_ERR_INVALID_ARGUMENT;
@@ -149,6 +151,7 @@ int qd_nearest_point_f32(const float* x, int prescaled, const float* points, int
     p.fine = (k > 32 && assign_mode == QD_ASSIGN_MIDPOINT) ? 1 : 0;      // the fine cell table of qd_transform.h
     int rc = 0;
     if (n > 0 && launch_prescaled_stream(p, bucket, (hipStream_t)stream, rc)) return rc;
+    if (n > 0 && !q) return QD_ERR_INVALID_ARGUMENT;                          // (n < 4, a bucket below 4 elements, or a misaligned base)
     return run_transform<MODE_NEAREST>(p, bucket, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

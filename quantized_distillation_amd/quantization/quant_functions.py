@@ -473,13 +473,16 @@ class SearchSorted:
         pts = _points_on(k, self.scaled_tensor.device)
         n = self.scaled_tensor.numel()
         idx = torch.empty(n, dtype=torch.int64, device=self.scaled_tensor.device)
-        scratch = torch.empty(n, dtype=torch.float32, device=self.scaled_tensor.device)
         one = torch.ones(1, dtype=torch.float32, device=pts.device)
         zero = torch.zeros(1, dtype=torch.float32, device=pts.device)
         ws = _lib.workspace(pts.device)
         if n > 0:
+            # indices only (q = NULL): 4 B read + 8 B written per element; the kernel wants n >= 4 and a 16-byte aligned base,
+            # the few-element / offset-view case writes its values into a throw-away buffer instead
+            only = n >= 4 and self.scaled_tensor.data_ptr() % 16 == 0
+            scratch = None if only else torch.empty(n, dtype=torch.float32, device=self.scaled_tensor.device)
             _lib.check(_lib.load().qd_nearest_point_f32(
-                self.scaled_tensor.data_ptr(), 1, pts.data_ptr(), pts.numel(), 1, scratch.data_ptr(),
+                self.scaled_tensor.data_ptr(), 1, pts.data_ptr(), pts.numel(), 1, None if only else scratch.data_ptr(),
                 idx.data_ptr(), 8, n, 0, one.data_ptr(), zero.data_ptr(), None, 0, 0.0,
                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         return idx

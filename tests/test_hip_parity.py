@@ -613,14 +613,35 @@ def test_fine_cell_table_with_crowded_and_degenerate_points(k):
                 got_i = host(idx).astype(np.int64)
                 assert np.array_equal(got_i, want_idx[:nn]), (k, name, bucket, nn, idx_bytes, np.flatnonzero(got_i != want_idx[:nn])[:5])
                 assert np.array_equal(host(q), want_q[:nn], equal_nan=True), (k, name, bucket, nn, idx_bytes)
+                # indices only (q == NULL, include/qd_hip.h): the same indices, nothing else written
+                idx2 = torch.full((nn,), 77, dtype=dt, device=DEV)
+                rc = lib.qd_nearest_point_f32(ud.data_ptr(), 1, pd.data_ptr(), k, 1, None, idx2.data_ptr(), idx_bytes, nn, bucket,
+                                              ab[0].data_ptr(), ab[1].data_ptr(), None, 0, 0.0, ws.data_ptr(), ws.numel(), st)
+                _lib.check(rc)
+                assert torch.equal(idx2, idx), (k, name, bucket, nn, idx_bytes, 'indices only')
+    # indices only is refused where the stream kernel cannot serve it, and without an index output
+    pd, ud = dev(np.array([0.0, 1.0], np.float32)), dev(np.zeros(64, np.float32))
+    ab = torch.ones(2, 64, device=DEV)
+    i8 = torch.zeros(64, dtype=torch.int64, device=DEV)
+    for args in ((1, None, i8.data_ptr(), 8, 3, 0), (1, None, None, 8, 64, 0), (0, None, i8.data_ptr(), 8, 64, 0), (1, None, i8.data_ptr(), 8, 64, 2)):
+        prescaled, qp, ip, ib, nn, bucket = args
+        assert lib.qd_nearest_point_f32(ud.data_ptr(), prescaled, pd.data_ptr(), 2, 1, qp, ip, ib, nn, bucket, ab[0].data_ptr(), ab[1].data_ptr(),
+                                        None, 0, 0.0, ws.data_ptr(), ws.numel(), st) == -1, args
 
 
 def test_search_sorted_handle_query():
+    """SearchSorted(tensor).query(points) (quant_functions.py:509-573): int64 indices by the midpoint rule.  The kernel writes
+    indices only (no throw-away q) when the tensor has at least 4 elements and a 16-byte aligned base; tiny tensors and views
+    at an odd offset take the form with a scratch q."""
     from quantization.quant_functions import SearchSorted
-    x = np.random.RandomState(0).rand(10000).astype(np.float32)
-    pts = np.array([0.0, 0.3, 0.31, 0.9], dtype=np.float32)
-    idx = SearchSorted(dev(x)).query(dev(pts))
-    assert np.array_equal(host(idx), onp.assign_midpoint(x, pts))
+    rng = np.random.RandomState(0)
+    for n, off in ((10000, 0), (1 << 20, 0), ((1 << 20) + 3, 0), (5, 0), (3, 0), (1, 0), (10000, 1), (4099, 3), (70001, 4)):
+        base = rng.rand(n + off).astype(np.float32)
+        x = base[off:]
+        for pts in (np.array([0.0, 0.3, 0.31, 0.9], dtype=np.float32), np.sort(rng.rand(100)).astype(np.float32)):
+            idx = SearchSorted(dev(base)[off:]).query(dev(pts))
+            assert idx.dtype == torch.int64 and idx.numel() == n
+            assert np.array_equal(host(idx), onp.assign_midpoint(x, pts)), (n, off, pts.size)
 
 
 def test_init_points_and_huffman_golden(golden_misc):
