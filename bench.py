@@ -210,6 +210,22 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
         trainers[mode] = DistillTrainer(models.student(), models.teacher(), dev, num_bits=4, bucket_size=256, mode=mode)
         for i in range(warmup):
             trainers[mode].step(*batches[i % 4])
+    # third leg: the multi-tensor step replayed from hipGraphs (quantize + forward + loss + backward in one graph, the
+    # optimizer in a second, the RCCL all-reduce eager between the two): the ~150 launches of a step stop depending on the
+    # host, which is where the repetition-to-repetition spread of the eager legs comes from
+    graph_error = None
+    try:
+        torch.manual_seed(0)
+        tg = DistillTrainer(models.student(), models.teacher(), dev, num_bits=4, bucket_size=256, mode='multi')
+        for i in range(warmup):
+            tg.step(*batches[i % 4])
+        tg.capture(*batches[0])
+        for i in range(warmup):
+            tg.step(*batches[i % 4])
+        trainers['multi_graph'] = tg
+        modes = modes + ('multi_graph',)
+    except Exception as e:                                  # noqa: BLE001 -- reported in the JSON, the eager legs still run
+        graph_error = '%s: %s' % (type(e).__name__, e)
 
     def timed_repetition(tr):
         torch.cuda.synchronize()
@@ -244,6 +260,13 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
         dt = statistics.median(reps[mode])
         # per-phase breakdown (each phase bracketed by synchronize; serialised, so the sum exceeds the step)
         phases = {}
+        if mode == 'multi_graph':
+            sps = sorted(steps / r for r in reps[mode])
+            out[mode] = {'steps_per_sec': round(steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
+                         'samples_per_sec': round(steps * per_gpu_batch * n_gpus / dt, 1), 'statistic': 'median of %d repetitions' % REPS,
+                         'steps_per_sec_min': round(sps[0], 1), 'steps_per_sec_max': round(sps[-1], 1),
+                         'steps_per_sec_repetitions': [round(steps / r, 1) for r in reps[mode]]}
+            continue
 
         def timed(name, fn, nrep=20):
             torch.cuda.synchronize()
@@ -269,11 +292,19 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
                                   'per_tensor faster in every repetition' if lo_p > hi_m else
                                   'indistinguishable: the repetition ranges overlap (the quantizer is %.3f / %.3f ms of the step)'
                                   % (out['multi']['phases']['quantize_ms'], out['per_tensor']['phases']['quantize_ms']))
+    if 'multi_graph' in out:
+        lo_g, hi_g = out['multi_graph']['steps_per_sec_min'], out['multi_graph']['steps_per_sec_max']
+        out['multi_graph_vs_multi'] = ('graph replay faster in every repetition' if lo_g > hi_m else
+                                       'eager faster in every repetition' if lo_m > hi_g else
+                                       'indistinguishable: the repetition ranges overlap')
     trainers.clear()
+    if graph_error is not None:
+        out['multi_graph'] = {'error': graph_error}
     out['note'] = ("'multi' = one multi-tensor quantize launch per step on persistent shadows (K9); 'per_tensor' = the "
-                   "reference's loop shape (22 uniformQuantization calls + restore).  hipGraph replay of the step "
-                   "(DistillTrainer.capture) measured no gain: the step is bound by MIOpen's small-shape conv kernels, "
-                   "not by launches (profiles/r01_distill_notes.txt)")
+                   "reference's loop shape (22 uniformQuantization calls + restore); 'multi_graph' = the 'multi' step replayed "
+                   "from two hipGraphs (DistillTrainer.capture; tests/test_hip_distill.py::test_graph_replay_matches_eager): the "
+                   "GPU work is the same MIOpen small-shape kernels, but ~150 launches per step no longer wait for the host, so "
+                   "the repetitions stop spreading")
     return out
 
 
