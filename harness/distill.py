@@ -191,40 +191,61 @@ class DistillTrainer(object):
     # ------------------------------------------------------------------ hipGraph replay of the step
     _graph_fb = None
 
-    def capture(self, images, labels, warmup=3):
+    def capture(self, *batch, warmup=3):
         """Capture the launch-bound part of the step in hipGraphs (torch.cuda.CUDAGraph): graph A =
-        multi-tensor quantize + student/teacher forward + KD loss + backward, graph B = the SGD
+        multi-tensor quantize + student/teacher forward + KD loss + backward, graph B = gradient clipping + the SGD
         update.  The gradient all-reduce stays between the two replays (eager RCCL call), so the
         distributed step is  A.replay(); all_reduce; B.replay().  Only for mode='multi'."""
+        self.capture_shapes([batch], warmup=warmup)
+
+    def capture_shapes(self, batches, warmup=3):
+        """capture() for batches of SEVERAL shapes (the token batches of the seq2seq loop differ in length): one graph A per
+        distinct shape, each with its own static input buffers, all sharing one memory pool and the one graph B."""
         assert self.mode == 'multi', 'graph capture needs the persistent-shadow (multi) mode'
         assert self.style == 'none' and self.every == 1 and self._since >= 1, \
             'graph capture covers the plain every-step STE loop only'
+        assert self.sync._layout is None or not self.sync.active, \
+            'graph capture keeps the all-reduce between the two graphs: not with the overlap hooks of a multi-rank run'
         self.side = None                                 # one captured stream; the graph orders the kernels itself
-        self._sx, self._sy = images.clone(), labels.clone()
+        shapes = {}
+        for b in batches:
+            shapes.setdefault(tuple(tuple(t.shape) for t in b), tuple(t.clone() for t in b))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                      # materialises momentum buffers, cudnn/miopen plans
-                self.quantize()
-                self.forward_backward(self._sx, self._sy)
-                self.opt.step()
+                for sb in shapes.values():
+                    self.quantize()
+                    self.forward_backward(*sb)
+                    self.clip()
+                    self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            self.quantize()
-            self._sloss = self.forward_backward(self._sx, self._sy)
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        self._graphs, pool = {}, None
+        for key, sb in shapes.items():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=side):     # the warm-up stream: its BLAS handles / workspaces exist
+                self.quantize()
+                loss = self.forward_backward(*sb)
+            pool = g.pool()
+            self._graphs[key] = (sb, g, loss)
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, pool=pool, stream=side):
+            self.clip()
             self.opt.step()
-        self._graph_fb, self._graph_opt = ga, gb
+        self._graph_fb, self._graph_opt = self._graphs, gb
 
-    def _step_graph(self, images, labels):
-        self._sx.copy_(images, non_blocking=True)
-        self._sy.copy_(labels, non_blocking=True)
-        self._graph_fb.replay()
+    def _step_graph(self, *batch):
+        entry = self._graphs.get(tuple(tuple(t.shape) for t in batch))
+        if entry is None:
+            raise ValueError('no graph was captured for a batch of shapes %r' % ([tuple(t.shape) for t in batch],))
+        sb, g, loss = entry
+        for dst, src in zip(sb, batch):
+            dst.copy_(src, non_blocking=True)
+        g.replay()
         self.sync.sync()
         self._graph_opt.replay()
-        return self._sloss
+        return loss
 
 
 class TeacherAhead(object):
