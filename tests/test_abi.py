@@ -51,6 +51,30 @@ def test_host_only_entry_points(lib):
     assert lib.qd_num_buckets(77, 0) == 1 and lib.qd_padded_length(77, 0) == 77
 
 
+def test_every_compute_entry_point_checks_its_arguments_before_touching_the_device(lib):
+    """Error behaviour of the boundary (include/qd_hip.h): null tensors with a non-zero length, zero levels / points, no
+    workspace -- every compute entry point returns QD_ERR_INVALID_ARGUMENT without a launch (this runs on a box without a
+    GPU), the way the reference's functions raise ValueError before any work (quant_functions.py:22-33,230-236)."""
+    import ctypes
+    host_only = {'qd_abi_version', 'qd_target_arch', 'qd_error_string', 'qd_workspace_bytes', 'qd_set_single_fused_mode', 'qd_num_buckets',
+                 'qd_padded_length', 'qd_multi_plan', 'qd_multi_global_plan', 'qd_multi_dq_plan', 'qd_packed_bytes',
+                 'qd_order_stats_workspace_bytes'}
+    checked = 0
+    for name, (res, args) in sorted(_lib.SIGNATURES.items()):
+        if name in host_only:
+            continue
+        assert res is ctypes.c_int, name
+        vals = [100 if a in (ctypes.c_int64, ctypes.c_uint64) else 0 if a in (ctypes.c_int, ctypes.c_size_t) else 0.0 if a is ctypes.c_float
+                else None for a in args]
+        assert getattr(lib, name)(*vals) == -1, name
+        checked += 1
+    assert checked >= 24
+    # the indices-only form of the nearest-point call needs the pre-scaled input and an index output
+    assert lib.qd_nearest_point_f32(None, 0, None, 4, 1, None, None, 8, 100, 256, None, None, None, 0, 0.0, None, 0, None) == -1
+    assert lib.qd_selftest_div_invariant(1, 10, 6, None, None) == -1          # families 0 .. 5
+    assert lib.qd_point_grad_f32(None, None, 3, None, 10, 256, 4, None, None, 0, None) == -1      # index width 1 or 8
+
+
 def test_multi_plan_host(lib):
     T = (_lib.QdTensorDesc * 4)()
     for i, n in enumerate([800000, 10, 0, 1025]):
