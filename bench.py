@@ -219,13 +219,20 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
         tg = DistillTrainer(models.student(), models.teacher(), dev, num_bits=4, bucket_size=256, mode='multi')
         for i in range(warmup):
             tg.step(*batches[i % 4])
-        tg.capture(*batches[0])
+        tg.capture(*batches[0])                             # local: no collective inside
+    except Exception as e:                                  # noqa: BLE001 -- reported in the JSON, the eager legs still run
+        graph_error = '%s: %s' % (type(e).__name__, e)
+    if distributed:
+        # every rank must run the same legs (each holds collectives): the leg is dropped everywhere if the capture failed anywhere
+        ok = torch.tensor([0 if graph_error else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            graph_error = graph_error or 'graph capture failed on another rank'
+    if graph_error is None:
         for i in range(warmup):
             tg.step(*batches[i % 4])
         trainers['multi_graph'] = tg
         modes = modes + ('multi_graph',)
-    except Exception as e:                                  # noqa: BLE001 -- reported in the JSON, the eager legs still run
-        graph_error = '%s: %s' % (type(e).__name__, e)
 
     def timed_repetition(tr):
         torch.cuda.synchronize()
