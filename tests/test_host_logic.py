@@ -200,3 +200,40 @@ def test_bucket_invariant_division_in_exact_arithmetic():
     assert st['normal'][0] > 10000 and st['normal'][1] == 0
     assert st['zero'][1] == 0
     assert st['denormal'][0] > 500
+
+
+def test_committed_bench_lines_keep_the_contract_and_are_self_consistent():
+    """The bench.py lines committed under profiles/ carry every key the driver's contract names, and their numbers agree with
+    each other: roofline.achieved = algorithmic bytes / average launch time, frac = achieved / peak, value = the same bytes /
+    ms_per_step (whole call, so never above the kernel's own rate), measured traffic within 2 % of the algorithmic bytes."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r03_bench*.json')))
+    assert len(files) >= 3
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                    'dtype', 'data', 'config', 'roofline'):
+            assert key in d, (f, key)
+        assert d['metric'] == 'quantize_dequantize_GBps_64M_fp32_4bit' and d['unit'] == 'GB/s' and d['dtype'] == 'f32'
+        assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and 'workload' in d['config']
+        r = d['roofline']
+        for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+            assert key in r, (f, key)
+        assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and r['unit'] == 'GB/s'
+        algo = r['algorithmic_bytes_per_launch']
+        assert algo == 8 * d['config']['n_elements_per_gpu']
+        assert abs(r['achieved'] - algo / r['avg_launch_us'] / 1e3) <= 1e-3 * r['achieved'], f
+        assert abs(r['frac'] - r['achieved'] / r['peak']) <= 1e-3
+        whole = d['n_gpus'] * algo / (d['ms_per_step'] * 1e-3) / 1e9
+        assert abs(d['value'] - whole) <= 2e-3 * whole, (f, d['value'], whole)
+        assert d['value'] <= r['achieved'] * 1.001
+        if r['traffic'] is not None:
+            assert 0.98 * algo <= r['traffic'] <= 1.02 * algo, (f, r['traffic'])
+        if 'cpu_baseline' in d and d['cpu_baseline']:
+            c = d['cpu_baseline']
+            for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+                assert key in c, (f, key)
+            assert c['kind'] in ('reference', 'port') and c['value'] < d['value'] / 100
