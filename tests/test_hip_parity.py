@@ -3,7 +3,6 @@ golden vectors produced by the reference and against the CPU oracle.
 
 Bar: bit-exact for q, alpha, beta, arg indices, level indices and point indices; tolerance only
 where an fp32 summation order is involved (mean, point gradient, 'complicated' STE sum)."""
-import ctypes
 import os
 
 import numpy as np

@@ -2,7 +2,6 @@
 (tests/golden/gen_golden.py).  Bit-exact everywhere except where the reference's own fp32
 summation order is involved (mean, point-gradient sums, the sparse-mm of the 'complicated' STE)."""
 import numpy as np
-import pytest
 
 from oracle import oracle_np as onp
 

@@ -3,7 +3,6 @@
 bucket of `extra` elements (plus, for the chunk kernels, the full buckets after the last whole chunk)."""
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
