@@ -221,14 +221,19 @@ __device__ __forceinline__ void merged_prefix_sums(const int (&id)[4], const flo
     s[3] = (((e03 ? m[0] : z) + (e13 ? m[1] : z)) + (e23 ? m[2] : z)) + m[3];
 }
 
-template <int KR>
+// HALF: the two half-waves share 32 columns (lane l and lane l + 32 of a wave: column l) and update them one after the other --
+// LDS operations of one wave complete in order, the wave barriers only pin the compiler -- so a [k][128] table serves a
+// 256-lane block: 64 KiB at k = 128, two blocks per CU, every wave on its own columns (no token to pass).
+template <int KR, bool HALF = false>
 struct PgBins {
     float acc[KR > 0 ? KR : 1];
     float* col;
     int stride;
-    __device__ __forceinline__ void init(float* lds_col, int stride_) {
+    int hi;                                                 // HALF: which half-wave this lane is in
+    __device__ __forceinline__ void init(float* lds_col, int stride_, int hi_ = 0) {
         col = lds_col;
         stride = stride_;
+        hi = hi_;
 #pragma unroll
         for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] = 0.0f;
     }
@@ -236,8 +241,15 @@ struct PgBins {
         if (KR > 0) {
 #pragma unroll
             for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] += (id == j) ? m : 0.0f;
-        } else {
+        } else if (!HALF) {
             col[id * stride] += m;                          // private column: plain LDS read-add-write
+        } else {
+            if (hi == 0) col[id * stride] += m;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (hi == 1) col[id * stride] += m;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     // four elements at once, for the large tables that leave one or two waves per CU: the four reads are
@@ -246,10 +258,25 @@ struct PgBins {
     __device__ __forceinline__ void add4_merged(const int (&id)[4], const float (&m)[4]) {
         float* a0 = col + id[0] * stride; float* a1 = col + id[1] * stride;
         float* a2 = col + id[2] * stride; float* a3 = col + id[3] * stride;
-        const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
         float s[4];
         merged_prefix_sums(id, m, s);
-        *a0 = c0 + s[0]; *a1 = c1 + s[1]; *a2 = c2 + s[2]; *a3 = c3 + s[3];
+        if (!HALF) {
+            const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
+            *a0 = c0 + s[0]; *a1 = c1 + s[1]; *a2 = c2 + s[2]; *a3 = c3 + s[3];
+        } else {
+            if (hi == 0) {
+                const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
+                *a0 = c0 + s[0]; *a1 = c1 + s[1]; *a2 = c2 + s[2]; *a3 = c3 + s[3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (hi == 1) {
+                const float c0 = *a0, c1 = *a1, c2 = *a2, c3 = *a3;
+                *a0 = c0 + s[0]; *a1 = c1 + s[1]; *a2 = c2 + s[2]; *a3 = c3 + s[3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 };
 
@@ -276,7 +303,7 @@ struct BucketWalk {
 
 // BK: 0 = one alpha for the tensor, 1 = bucket = element >> row_shift (power-of-two buckets), 2 = any bucket size >= 4
 // (BucketWalk: non-power-of-two sizes ran on the scalar kernel below before: 82-126 us against 54-58 us)
-template <int KR, int IDXB, int BK, int U, bool MERGE>
+template <int KR, int IDXB, int BK, int U, bool MERGE, bool HALF = false>
 __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const void* idx, const float* alpha, int64_t n,
                                                          int row_shift, int64_t row, int64_t nb, int k, float* part /* [grid][k] */) {
     // KR == 0: bins[k][BS] with BS = blockDim.x (256 for k <= 128, 128 for k <= 256, 64 for k <= 512:
@@ -287,12 +314,14 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
     const int64_t bbase = (int64_t)blockIdx.x * BS;         // block-uniform: lane 0's first float4
     const int64_t tid = bbase + tx;
     const int64_t nth = (int64_t)gridDim.x * BS;
+    const int C = HALF ? BS >> 1 : BS;                      // columns of the table
     if (KR == 0) {
-        for (int j = threadIdx.x; j < k * BS; j += BS) lds[j] = 0.0f;
+        for (int j = threadIdx.x; j < k * C; j += BS) lds[j] = 0.0f;
         __syncthreads();
     }
-    PgBins<KR> B;
-    B.init(lds + threadIdx.x, BS);
+    PgBins<KR, HALF> B;
+    if (HALF) B.init(lds + ((tx >> 6) << 5) + (tx & 31), C, (tx >> 5) & 1);
+    else B.init(lds + threadIdx.x, BS);
     const float a_single = BK != 0 ? 0.0f : alpha[0];
     const int64_t n4 = n >> 2;
     BucketWalk walk;
@@ -382,13 +411,13 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
             part[(int64_t)blockIdx.x * k + j] = (lds[j] + lds[KR + j]) + (lds[2 * KR + j] + lds[3 * KR + j]);
     } else {
         __syncthreads();
-        // 4 threads per bin, BS/4 columns each, rotated start (bank-conflict free), then a fixed fold
-        const int quarter = BS >> 2;
+        // 4 threads per bin, C/4 columns each, rotated start (bank-conflict free), then a fixed fold
+        const int quarter = C >> 2;
         for (int t = threadIdx.x; t < ((k * 4 + 3) & ~3); t += BS) {
             const int j = t >> 2, q = t & 3;
             float acc = 0.0f;
             if (j < k)
-                for (int c = 0; c < quarter; ++c) acc += lds[j * BS + q * quarter + ((c + j) & (quarter - 1))];
+                for (int c = 0; c < quarter; ++c) acc += lds[j * C + q * quarter + ((c + j) & (quarter - 1))];
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
             if (q == 0 && j < k) part[(int64_t)blockIdx.x * k + j] = acc;
@@ -1010,7 +1039,10 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     if (fast) {
         // k <= 4: register bins; otherwise an LDS table [k][threads] of lane-private columns
         const int threads = k <= 128 ? 256 : (k <= 256 ? 128 : 64);
-        const size_t lds_bytes = (size_t)(k <= 4 ? 4 * 4 : k * threads) * sizeof(float);
+        // 64 < k <= 128: the two half-waves of a wave share 32 columns -- a [k][128] table for the 256 lanes (<= 64 KiB, two
+        // blocks per CU) instead of four waves passing a token around [k][64]
+        const bool halves = k > 64 && k <= 128;
+        const size_t lds_bytes = (size_t)(k <= 4 ? 4 * 4 : k * (halves ? threads / 2 : threads)) * sizeof(float);
         // tables above 16 KiB leave few waves per CU: a resident grid (as many blocks as fit the CUs' LDS at
         // once, so the table is zeroed and folded once per CU), more loads in flight per lane, and the merged
         // four-element update that needs one LDS round trip per float4 instead of four
@@ -1020,9 +1052,9 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
             const int resident = num_cus() * per_cu;
             if (blocks > resident) blocks = resident;
         }
-#define QD_PG(KR, IDXB, BK, U, MG)                                                                                  \
+#define QD_PG(KR, IDXB, BK, U, MG, ...)                                                                             \
         {                                                                                                           \
-            auto kern = k_point_grad_fast<KR, IDXB, BK, U, MG>;                                                     \
+            auto kern = k_point_grad_fast<KR, IDXB, BK, U, MG, ##__VA_ARGS__>;                                      \
             if (lds_bytes > 64 * 1024)                                                                              \
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(KR > 0 ? 256 : threads), lds_bytes, st, g, idx, alpha, n,   \
@@ -1032,6 +1064,7 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
         {                                                                                                           \
             if (k <= 4) QD_PG(4, IDXB, BK, 4, false)                                                                \
             else if (!big) QD_PG(0, IDXB, BK, 4, false)                                                             \
+            else if (halves) QD_PG(0, IDXB, BK, 4, true, true)                                                      \
             else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
             else {                                           /* k > 64: four waves take turns on 64 columns */      \
                 const size_t tl = (size_t)k * 64 * sizeof(float);                                                   \
