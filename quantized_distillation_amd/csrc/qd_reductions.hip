@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_point_grad_fast(const float* g, const v
     }
 }
 
-// stage 1 for k > 64 points: G waves take TURNS on one set of 64 lane-private columns.
+// stage 1 for k > 128 points (64 < k <= 128: the half-wave columns of PgBins): G waves take TURNS on one set of 64 lane-private columns.
 // With one lane per column a [k][256 / 128 / 64] table (k <= 128 / 256 / 512) fills the LDS and leaves 4 / 2 / 1 waves per
 // CU, each paying the LDS round trip of every float4 (read 4 bins, add, write) AND its ~40 VALU instructions back to
 // back: 66 / 121 / 305 us for 64 Mi elements.  (An intermediate form -- two thread groups sharing the columns and
@@ -1066,7 +1066,7 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
             else if (!big) QD_PG(0, IDXB, BK, 4, false)                                                             \
             else if (halves) QD_PG(0, IDXB, BK, 4, true, true)                                                      \
             else if (lds_bytes <= 64 * 1024) QD_PG(0, IDXB, BK, 4, true)                                            \
-            else {                                           /* k > 64: four waves take turns on 64 columns */      \
+            else {                                           /* k > 128: four waves take turns on 64 columns */      \
                 const size_t tl = (size_t)k * 64 * sizeof(float);                                                   \
                 int per_cu_t = (int)((160 * 1024) / (tl + 64));   /* LDS; the 142-163 VGPRs allow 3 blocks per CU */  \
                 if (per_cu_t > kTurnsBlocksPerCu) per_cu_t = kTurnsBlocksPerCu;                                      \
