@@ -21,7 +21,13 @@ all-reduce of the steps/sec legs really runs through RCCL on a one-GPU box.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      achieved algorithmic GB/s of the dominant kernel (8 B/element: 4 read + 4 written,
-                SURVEY.md 8d) from HIP-event timing of the timed region, against the 8 TB/s peak
+                SURVEY.md 8d) from HIP-event timing of the timed region, against the 8 TB/s peak;
+                roofline.kernels: the same figure for every other kernel on the path (SURVEY 8d's
+                secondary rows, K2 ... K9, the multi-tensor kernels on the WRN-16-22 shape list),
+                HIP-event timed in this run by harness/kernel_bench.py.  The driver's record keeps
+                only the SCALARS of this object, so every row is also there as a short string
+                (k01, k02, ...), and so are the steps/sec and data-parallel figures of the
+                `distill` object (steps_cfg*, dp_cfg*): mirrors, the full objects stay in the line
   cpu_baseline  the REFERENCE's own uniformQuantization (staged bytecode of
                 /root/reference/quantization, oracle/ref_stage.py) timed on the host cores of this
                 box on the same workload, with the two ports (C/OpenMP, torch ops) next to it.
@@ -189,7 +195,10 @@ def cpu_distill_baseline(refq=None, steps=200, warmup=3, batch=50):
                       '(configs[0])' % (steps, warmup, batch)}
 
 
-def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, per_gpu_batch=50):
+from harness.dpbench import XGMI_PEAK_GBPS, dp_report, event_ms, flat_dp, timed_steps  # noqa: E402,F401
+
+
+def distill_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=100, warmup=20, per_gpu_batch=50):
     """Second half of BASELINE.json's metric: distilled-training steps/sec on synthetic
     CIFAR10-shaped data (configs[1]: ConvolForwardNet student, 4-bit uniform quantization, bucket
     256, pure STE), data parallel over the ranks with one RCCL all-reduce of the flat gradient
@@ -234,25 +243,6 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
         trainers['multi_graph'] = tg
         modes = modes + ('multi_graph',)
 
-    def timed_repetition(tr):
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            tr.step(*batches[i % 4])
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
-        return dt
-
     # The 2 ms step is ~150 small launches (MIOpen's small-shape convolutions, batch-norm, the optimizer) and its time
     # moves from repetition to repetition on one box (profiles/r03_distill_spread.txt).  So: REPS repetitions of `steps`
     # steps per mode, INTERLEAVED (multi, per_tensor, multi, ...) so that drift hits both alike; the MEDIAN is reported,
@@ -261,38 +251,29 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
     reps = {m: [] for m in modes}
     for _rep in range(REPS):
         for mode in modes:
-            reps[mode].append(timed_repetition(trainers[mode]))
+            tr = trainers[mode]
+            job, _own = timed_steps(lambda i, tr=tr: tr.step(*batches[i % 4]), steps, 1, dev, distributed)
+            reps[mode].append(job[0])
     for mode in modes:
         tr = trainers[mode]
         dt = statistics.median(reps[mode])
-        # per-phase breakdown (each phase bracketed by synchronize; serialised, so the sum exceeds the step)
-        phases = {}
-        if mode == 'multi_graph':
-            sps = sorted(steps / r for r in reps[mode])
-            out[mode] = {'steps_per_sec': round(steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
-                         'samples_per_sec': round(steps * per_gpu_batch * n_gpus / dt, 1), 'statistic': 'median of %d repetitions' % REPS,
-                         'steps_per_sec_min': round(sps[0], 1), 'steps_per_sec_max': round(sps[-1], 1),
-                         'steps_per_sec_repetitions': [round(steps / r, 1) for r in reps[mode]]}
-            continue
-
-        def timed(name, fn, nrep=20):
-            torch.cuda.synchronize()
-            a = time.perf_counter()
-            for _ in range(nrep):
-                fn()
-            torch.cuda.synchronize()
-            phases[name] = round((time.perf_counter() - a) / nrep * 1e3, 4)
-        x, y = batches[0]
-        timed('quantize_ms', tr.quantize)
-        timed('fwd_bwd_ms', lambda: tr.forward_backward(x, y))
-        timed('restore_ms', tr.restore)
-        timed('allreduce_ms', tr.sync.sync)
-        timed('optimizer_ms', tr.opt.step)
         sps = sorted(steps / r for r in reps[mode])
         out[mode] = {'steps_per_sec': round(steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 4),
                      'samples_per_sec': round(steps * per_gpu_batch * n_gpus / dt, 1), 'statistic': 'median of %d repetitions' % REPS,
                      'steps_per_sec_min': round(sps[0], 1), 'steps_per_sec_max': round(sps[-1], 1),
-                     'steps_per_sec_repetitions': [round(steps / r, 1) for r in reps[mode]], 'phases': phases}
+                     'steps_per_sec_repetitions': [round(steps / r, 1) for r in reps[mode]]}
+        if mode == 'multi_graph':
+            continue
+        # per-phase breakdown, each phase HIP-event timed on its own over >= 50 back-to-back calls (serialised, so the sum
+        # exceeds the step)
+        x, y = batches[0]
+        out[mode]['phases'] = {
+            'quantize_ms': round(event_ms(tr.quantize, 50), 4),
+            'fwd_bwd_ms': round(event_ms(lambda: tr.forward_backward(x, y), 20, precondition_s=0.05), 4),
+            'restore_ms': round(event_ms(tr.restore, 50, precondition_s=0.02), 4),
+            'allreduce_ms': round(event_ms(tr.sync.sync, 50, precondition_s=0.02), 4),
+            'optimizer_ms': round(event_ms(tr.opt.step, 50, precondition_s=0.02), 4),
+            'timing': 'HIP events, median of 3 repetitions of 20-50 calls after preconditioning'}
     lo_m, hi_m = out['multi']['steps_per_sec_min'], out['multi']['steps_per_sec_max']
     lo_p, hi_p = out['per_tensor']['steps_per_sec_min'], out['per_tensor']['steps_per_sec_max']
     out['multi_vs_per_tensor'] = ('multi faster in every repetition' if lo_m > hi_p else
@@ -304,6 +285,16 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
         out['multi_graph_vs_multi'] = ('graph replay faster in every repetition' if lo_g > hi_m else
                                        'eager faster in every repetition' if lo_m > hi_g else
                                        'indistinguishable: the repetition ranges overlap')
+    # the data-parallel figures of this config, on the graph-replay trainer when there is one (its all-reduce is the eager
+    # call between the two graphs), else on the eager multi-tensor one
+    best = 'multi_graph' if 'multi_graph' in trainers else 'multi'
+    tr = trainers[best]
+
+    def set_exchange(on, tr=tr):
+        tr.sync.active = on and tr.sync.world_active
+    out['dp'] = dp_report(lambda i: tr.step(*batches[i % 4]), steps, 3, dev, n_gpus, distributed, per_gpu_batch,
+                          tr.flat_grad.numel() * 4, set_exchange, tr.sync.sync if tr.sync.active else None, ctl_barrier, rank)
+    out['dp']['trainer'] = best
     trainers.clear()
     if graph_error is not None:
         out['multi_graph'] = {'error': graph_error}
@@ -315,13 +306,12 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, steps=100, warmup=20, 
     return out
 
 
-def dp_config_steps_per_sec(kind, dev, rank, n_gpus, distributed, steps=10, warmup=3):
+def dp_config_steps_per_sec(kind, dev, rank, n_gpus, distributed, ctl_barrier, steps=10, warmup=3, reps=3):
     """BASELINE configs[3] (kind='imagenet': ImageNet-shaped synthetic, resnet_kfilters
     resnet18(k=1.5) student distilled from a ResNet-34-shaped teacher, 4-bit bucketed, first/last
     tensors not quantized, DP over 8 GPUs) and configs[4] (kind='nmt': 2-layer LSTM seq2seq,
     multi30k-shaped synthetic tokens, 4-bit quantized distillation, DP over 4 GPUs).  Data
     parallel with the flat-gradient RCCL all-reduce, cut in 4 pieces overlapped with backward."""
-    import torch.distributed as dist
     from harness import models
     from harness.distill import (DistillTrainer, seq2seq_kd_loss_fn, synthetic_batch, synthetic_token_batch)
     torch.manual_seed(0)
@@ -346,44 +336,29 @@ def dp_config_steps_per_sec(kind, dev, rank, n_gpus, distributed, steps=10, warm
                 'SGD lr 1.0, clip-norm 5; 4-bit uniform, bucket 256')
     for i in range(warmup):
         tr.step(*batches[i % 2])
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        tr.step(*batches[i % 2])
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    phases = {}
 
-    def timed(name, fn, reps=5):
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        phases[name] = round((time.perf_counter() - a) / reps * 1e3, 3)
-    timed('quantize_ms', tr.quantize)
-    timed('fwd_bwd_ms (+overlapped all-reduce launch)', lambda: (tr.forward_backward(*batches[0]), tr.sync.sync()))
-    timed('optimizer_ms', tr.opt.step)
-    out = {'config': desc, 'per_gpu_batch': per_gpu, 'global_batch': per_gpu * n_gpus, 'n_gpus': n_gpus,
-           'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2),
-           'samples_per_sec': round(steps * per_gpu * n_gpus / dt, 1), 'steps': steps, 'phases': phases,
-           'gradient_bytes_per_step': int(tr.flat_grad.numel() * 4)}
+    def set_exchange(on):
+        tr.sync.active = on and tr.sync.world_active
+    out = {'config': desc}
+    out.update(dp_report(lambda i: tr.step(*batches[i % 2]), steps, reps, dev, n_gpus, distributed, per_gpu,
+                         tr.flat_grad.numel() * 4, set_exchange, tr.sync.sync if tr.sync.active else None, ctl_barrier, rank))
+    out['gradient_bytes_per_step'] = int(tr.flat_grad.numel() * 4)
+    out['allreduce_shape'] = ('%d asynchronous RCCL all-reduces (ReduceOp.AVG) of ~equal bytes, launched from the backward hooks in '
+                              'gradient-arrival order' % len(tr.sync.bounds)) if tr.sync.active else 'none (one rank, not forced)'
+    out['phases'] = {
+        'quantize_ms': round(event_ms(tr.quantize, 50), 4),
+        'fwd_bwd_ms (+overlapped all-reduce launch)': round(event_ms(lambda: (tr.forward_backward(*batches[0]), tr.sync.sync()), 5, precondition_s=0.0, reps=2), 3),
+        'optimizer_ms': round(event_ms(tr.opt.step, 20, precondition_s=0.02), 4),
+        'timing': 'HIP events; quantize: median of 3 x 50 launches after 100 ms of preconditioning'}
+    nq = sum(m.numel() for m, q in zip(tr.masters, tr.quantized) if q)
+    out['phases']['quantize_GBps'] = round(8 * nq / (out['phases']['quantize_ms'] * 1e-3) / 1e9, 1)
+    out['phases']['quantize_frac_of_8TBps'] = round(out['phases']['quantize_GBps'] / HBM_PEAK_GBPS, 4)
     del tr
     torch.cuda.empty_cache()
     return out
 
 
-def diffquant_steps_per_sec(dev, rank=0, n_gpus=1, distributed=False, steps=8, warmup=2, batch=100):
+def diffquant_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=8, warmup=2, batch=100, reps=3):
     """BASELINE configs[2]: CIFAR10 WideResNet-16-22 student (60 tensors, 82.7 M parameters), 2-bit
     (k = 4 points) non-uniform differentiable quantization, bucket 256: steps/sec of the
     optimize_quantization_points loop with the per-step quantizer cost broken out.  Quoted on 1 GPU;
@@ -400,45 +375,33 @@ def diffquant_steps_per_sec(dev, rank=0, n_gpus=1, distributed=False, steps=8, w
     x, y = synthetic_batch(batch, dev, seed=11 + 1000 * rank)
     for _ in range(warmup):
         tr.step(x, y)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(x, y)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    phases = {}
+    exchanging = tr.exchange
 
-    def timed(name, fn, reps=5):
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        phases[name] = round((time.perf_counter() - a) / reps * 1e3, 3)
-    timed('assign_all_tensors_ms (multi-tensor K5, 1 launch)', tr.quantize)
-    timed('fwd_bwd_ms', lambda: tr.forward_backward(x, y))
-    timed('point_gradients_ms (multi-tensor K6, 2 launches)', tr.point_gradients)
+    def set_exchange(on):
+        tr.exchange = on and exchanging
+
+    def exchange_once():
+        dist.all_reduce(tr.points_grad)
     nparams = sum(p.numel() for p in tr.params)
-    return {'config': 'Wide_ResNet depth 16 widen 22 (60 tensors, %.1f M params), k=4 points (2-bit) per tensor, bucket 256, '
-                      'percentile init, KD loss vs the unquantized model, SGD on the points; batch %d synthetic CIFAR10-shaped'
-                      % (nparams / 1e6, batch),
-            'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2), 'steps': steps,
-            'n_gpus': n_gpus, 'per_gpu_batch': batch, 'samples_per_sec': round(steps * batch * n_gpus / dt, 1),
-            'exchanged_bytes_per_step': int(tr.points_grad.numel() * 4) if tr.exchange else 0,
-            'setup_s': round(setup_s, 2), 'phases': phases,
-            'reference_cpu_quantizer_note': 'reference per-step quantizer cost on this model, CPU path: ~2.5 s per 16 Mi-element '
-                                            'tensor (BASELINE.md section 3); here the 60-tensor assign + point-gradient pair is the '
-                                            'two phase entries above'}
+    out = {'config': 'Wide_ResNet depth 16 widen 22 (60 tensors, %.1f M params), k=4 points (2-bit) per tensor, bucket 256, '
+                     'percentile init, KD loss vs the unquantized model, SGD on the points; batch %d synthetic CIFAR10-shaped'
+                     % (nparams / 1e6, batch)}
+    out.update(dp_report(lambda i: tr.step(x, y), steps, reps, dev, n_gpus, distributed, batch,
+                         tr.points_grad.numel() * 4 if exchanging else 0, set_exchange, exchange_once if exchanging else None,
+                         ctl_barrier, rank))
+    out['setup_s'] = round(setup_s, 2)
+    ph = {'assign_all_tensors_ms (multi-tensor K5, 1 launch)': round(event_ms(tr.quantize, 50), 4),
+          'fwd_bwd_ms': round(event_ms(lambda: tr.forward_backward(x, y), 3, precondition_s=0.0, reps=2), 3),
+          'point_gradients_ms (multi-tensor K6, 2 launches)': round(event_ms(tr.point_gradients, 50), 4),
+          'timing': 'HIP events; K5m / K6m: median of 3 x 50 launches after 100 ms of preconditioning'}
+    nq = sum(tr.params[i].numel() for i in tr.slots)
+    ph['assign_GBps (9 B/elem)'] = round(9 * nq / (ph['assign_all_tensors_ms (multi-tensor K5, 1 launch)'] * 1e-3) / 1e9, 1)
+    ph['point_gradients_GBps (5 B/elem)'] = round(5 * nq / (ph['point_gradients_ms (multi-tensor K6, 2 launches)'] * 1e-3) / 1e9, 1)
+    out['phases'] = ph
+    out['reference_cpu_quantizer_note'] = ('reference per-step quantizer cost on this model, CPU path: ~2.5 s per 16 Mi-element '
+                                           'tensor (BASELINE.md section 3); here the 60-tensor assign + point-gradient pair is the '
+                                           'two phase entries above')
+    return out
 
 
 def load_pmc_traffic():
@@ -520,18 +483,21 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline rows (roofline.kernels)')
     ap.add_argument('--no-distill', action='store_true', help='skip the distilled-training steps/sec leg')
     ap.add_argument('--no-diffquant', action='store_true', help='skip the WideResNet differentiable-quantization leg')
     ap.add_argument('--no-dp-configs', action='store_true', help='skip the ImageNet-shaped and seq2seq steps/sec legs')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 PMC passes that measure the HBM traffic of the headline kernel')
+    ap.add_argument('--deadline-s', type=float, default=1500.0,
+                    help='after this many seconds rank 0 prints the line with what has been measured so far and the run ends')
     ap.add_argument('--pmc-slice', action='store_true', help=argparse.SUPPRESS)       # child mode of measure_pmc_traffic()
     args = ap.parse_args()
     if args.pmc_slice:
         pmc_slice()
         return
 
-    from harness import launch
+    from harness import launch, legs
     if args.gpus > 1 and not launch.under_launcher():
         # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, RCCL over xGMI
         if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
@@ -560,19 +526,37 @@ def main():
     import torch.distributed as dist
     distributed = world > 1                  # the timed region's barriers: only where there is somebody to wait for
     rccl_error = None
+    legs.rccl_env_defaults()                 # a timed-out collective raises on the waiting ranks instead of ending them
     if launch.under_launcher():
-        dist.init_process_group('nccl', device_id=dev)        # "nccl" is RCCL on ROCm
+        dist.init_process_group('nccl', device_id=dev, timeout=legs.data_timeout())        # "nccl" is RCCL on ROCm
     else:
         # single process: still a (one-rank) RCCL group, and QD_FORCE_DIST=1 makes the harness issue its
         # collectives in it, so that the all-reduce path of the steps/sec legs is executed and timed on this box
         try:
             dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % launch.free_port(), rank=0, world_size=1,
-                                    device_id=dev)
+                                    device_id=dev, timeout=legs.data_timeout())
             os.environ['QD_FORCE_DIST'] = '1'
         except Exception as e:                                 # noqa: BLE001 -- keep the headline measurement
             rccl_error = '%s: %s' % (type(e).__name__, e)
     n_gpus = world
     rccl_world_size = dist.get_world_size() if dist.is_initialized() else None
+    runner = legs.LegRunner()                # the per-leg agreement runs over its own gloo group (harness/legs.py)
+
+    # the line as far as it has been measured: what the deadline prints if the run does not finish
+    line = {'metric': 'quantize_dequantize_GBps_64M_fp32_4bit', 'value': None, 'unit': 'GB/s', 'n_gpus': n_gpus, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic'}
+
+    def emit(extra=None):
+        d = dict(line)
+        d.update(extra or {})
+        os.write(saved_stdout_fd, (json.dumps(d) + '\n').encode())
+
+    def expired():
+        if rank == 0:
+            emit({'error': 'deadline of %.0f s reached: the line holds what had been measured by then' % args.deadline_s,
+                  'legs_failed': runner.history})
+    deadline = legs.Deadline(args.deadline_s, expired)
 
     import quantization
     from quantized_distillation_amd import _lib
@@ -619,12 +603,12 @@ def main():
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    event_ms = ev0.elapsed_time(ev1)
+    event_ms_total = ev0.elapsed_time(ev1)
 
     if distributed:
-        t = torch.tensor([elapsed, event_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, event_ms_total], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, event_ms = float(t[0]), float(t[1])
+        elapsed, event_ms_total = float(t[0]), float(t[1])
 
     # the same measurement over >= 200 launches whatever --steps says (the driver's --steps 20 region is 1.8 ms)
     ext_n = max(200, args.steps)
@@ -649,114 +633,141 @@ def main():
     c1.record()
     torch.cuda.synchronize()
     copy_gbps = ALGO_BYTES_PER_ELEM * N_ELEM * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del ya
+
+    bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM
+    kernel_us = event_ms_total * 1e3 / args.steps
+    achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+    committed = load_pmc_traffic()
+    roofline = {
+        'bound': 'hbm', 'kernel': 'k_bucket_vec<MODE_QDQ,16,4>',
+        'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBPS, 4),
+        'traffic': int(round(committed)) if committed else None,
+        'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on a '
+                          'builder box (committed file, NOT measured in this run)',
+        'traffic_committed': int(round(committed)) if committed else None,
+        'extended': {'launches': ext_n, 'avg_launch_us': round(ext_us, 3),
+                     'frac': round(bytes_per_launch / (ext_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)},
+        'extended_avg_launch_us': round(ext_us, 3),
+        'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
+        'timing': 'HIP events on the launch stream around the %d timed launches (includes inter-launch gaps)' % args.steps,
+        'torch_d2d_copy_GBps': round(copy_gbps, 1),      # torch's own copy of the same bytes, same box (a hand-written NT copy reaches 6.3-6.5 TB/s: profiles/r01_kbench.txt)
+    }
+    line.update({
+        'value': round(bytes_per_launch * args.steps * n_gpus / elapsed / 1e9, 2),
+        'ms_per_step': round(elapsed * 1e3 / args.steps, 5),
+        'config': {
+            'workload': 'uniformQuantization(x, s=16, bucket_size=256), x = randn(64Mi) fp32 per GPU (BASELINE configs[1] hot path, '
+                        'headline size)',
+            'call': 'quantization.uniformQuantization(x, s=16, type_of_scaling="linear", bucket_size=256), deterministic rounding, '
+                    'through the public API (result allocation + one launch through the C ABI)',
+            'n_elements_per_gpu': N_ELEM, 'levels': LEVELS, 'bucket_size': BUCKET,
+            'algorithmic_bytes_per_element': ALGO_BYTES_PER_ELEM, 'rotating_buffers': N_ROTATE, 'precondition_launches': n_pre,
+            'parallelism': 'independent tensors per rank (no data-path collective)' if n_gpus > 1 else 'single GPU',
+        },
+        'cpu_baseline': None, 'distill': None,
+        'parity_bit_exact_vs_oracle': None, 'parity_bit_exact_vs_reference': None,
+        'rccl_world_size': rccl_world_size, 'rccl_error': rccl_error, 'device': torch.cuda.get_device_name(dev),
+        'roofline': roofline,                             # last: the driver keeps the tail of the line
+    })
 
     # HBM traffic of the headline kernel, measured now (rank 0, N=1; after the timed regions, in a child process)
-    traffic_measured = None
     if rank == 0 and n_gpus == 1 and not args.no_pmc:
         try:
             traffic_measured = measure_pmc_traffic()
         except Exception as e:                                    # noqa: BLE001
             traffic_measured = {'error': '%s: %s' % (type(e).__name__, e)}
+        roofline['traffic_measured'] = traffic_measured
+        if traffic_measured.get('bytes_per_launch'):
+            roofline['traffic'] = int(traffic_measured['bytes_per_launch'])
+            roofline['traffic_source'] = 'measured in this run (traffic_measured)'
+            roofline['traffic_over_algorithmic'] = traffic_measured['over_algorithmic']
 
     # cpu_baseline leg (rank 0, N=1 only): the oracle is timed on the host cores and, in the same leg,
     # used as the checker of the GPU result computed above (bit-exact comparison)
-    parity = None
-    parity_ref = None
-    cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         q, sf = quantization.uniformQuantization(xs[0], LEVELS, bucket_size=BUCKET)
         try:
             cpu = cpu_baseline(x_host, q.cpu().numpy(), sf.alpha.cpu().numpy().reshape(-1))
-            parity = cpu.pop('gpu_result_bit_exact')
-            parity_ref = cpu.pop('gpu_result_bit_exact_vs_reference', None)
+            line['parity_bit_exact_vs_oracle'] = cpu.pop('gpu_result_bit_exact')
+            line['parity_bit_exact_vs_reference'] = cpu.pop('gpu_result_bit_exact_vs_reference', None)
         except Exception as e:                                    # noqa: BLE001  (keep the headline; say what failed)
             import traceback
             sys.stderr.write(traceback.format_exc())
             cpu = {'error': '%s: %s' % (type(e).__name__, e)}
+        line['cpu_baseline'] = cpu
         del q, sf
+    del live[:], xs[:]
+    torch.cuda.empty_cache()
 
-    # The steps/sec legs are reported alongside the headline; a failure in one of them (say, an out-of-memory
-    # condition on a shared box) is recorded in the JSON instead of losing the headline measurement above.
-    def leg(fn, *a, **kw):
-        try:
-            return fn(*a, **kw)
-        except Exception as e:                                    # noqa: BLE001
-            import traceback
-            sys.stderr.write(traceback.format_exc())
-            return {'error': '%s: %s' % (type(e).__name__, e)}
-
-    distill = None
-    if not args.no_distill:
-        del live[:], xs[1:]
+    # Per-kernel roofline rows (every rank measures its own GPU; rank 0's rows are reported): no collective inside.
+    if not args.no_kernels:
+        from harness import kernel_bench
+        rows = runner.run('kernels', kernel_bench.run, dev, collective=False)
+        roofline['kernels'] = rows
+        roofline['kernels_method'] = ('HIP events, median of %d repetitions of %d launches (12 for the 1 Gi-symbol histograms) after >= 100 ms '
+                                      'of preconditioning, >= 3 rotating buffer sets' % (kernel_bench.REPS, kernel_bench.ITERS))
         torch.cuda.empty_cache()
-        distill = leg(distill_steps_per_sec, dev, rank, n_gpus, distributed)
+
+    # The steps/sec legs are reported alongside the headline.  A failure in one of them (say, an out-of-memory condition
+    # on one rank) is recorded in the JSON instead of losing the headline measurement above, and cannot leave the other
+    # ranks inside a collective for longer than the group's timeout: runner.run() wraps the leg BODY and ends every leg
+    # with an agreement over a gloo group (harness/legs.py).
+    if not args.no_distill:
+        distill = {}
+        line['distill'] = distill
+        distill['cifar_student'] = runner.run('cifar_student', distill_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier)
+        torch.cuda.empty_cache()
         if not args.no_diffquant:
+            distill['diffquant_wrn'] = runner.run('diffquant_wrn', diffquant_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier)
             torch.cuda.empty_cache()
-            distill['diffquant_wrn'] = leg(diffquant_steps_per_sec, dev, rank, n_gpus, distributed)
         # configs[3] is quoted on 8 GPUs and configs[4] on 4; both fit one GPU, so they are timed at every N
         # (weak scaling: per-GPU batch fixed) and the driver's --gpus 8 / --gpus 4 runs give BASELINE's placements
         if not args.no_dp_configs:
+            distill['imagenet_resnet18k_dp'] = runner.run('imagenet_resnet18k_dp', dp_config_steps_per_sec, 'imagenet', dev, rank, n_gpus,
+                                                          distributed, runner.barrier)
             torch.cuda.empty_cache()
-            distill['imagenet_resnet18k_dp'] = leg(dp_config_steps_per_sec, 'imagenet', dev, rank, n_gpus, distributed)
-            torch.cuda.empty_cache()
-            distill['nmt_lstm_dp'] = leg(dp_config_steps_per_sec, 'nmt', dev, rank, n_gpus, distributed)
+            distill['nmt_lstm_dp'] = runner.run('nmt_lstm_dp', dp_config_steps_per_sec, 'nmt', dev, rank, n_gpus, distributed, runner.barrier)
+        if runner.history:
+            distill['legs_failed'] = [{'leg': n, 'ranks': r} for n, r in runner.history]
+
+    # the scalars the driver's record keeps (it drops nested objects): steps/sec + data-parallel figures, then the kernel rows
+    if line['distill']:
+        d = line['distill']
+        cs = d.get('cifar_student') or {}
+        if 'multi' in cs:
+            roofline['steps_cfg1'] = ' | '.join('%s %.1f (%.1f-%.1f)' % (m, cs[m]['steps_per_sec'], cs[m]['steps_per_sec_min'], cs[m]['steps_per_sec_max'])
+                                                for m in ('multi_graph', 'multi', 'per_tensor') if 'steps_per_sec' in (cs.get(m) or {}))[:118]
+            roofline['dp_cfg1'] = flat_dp(cs.get('dp'))
+        else:
+            roofline['steps_cfg1'] = flat_dp(cs)
+        for key, tag in (('diffquant_wrn', 'dp_cfg2_wrn_diffquant'), ('imagenet_resnet18k_dp', 'dp_cfg3_imagenet'), ('nmt_lstm_dp', 'dp_cfg4_nmt')):
+            if key in d:
+                roofline[tag] = flat_dp(d[key])
+    if isinstance(roofline.get('kernels'), list):
+        from harness.kernel_bench import flat_row
+        for i, r in enumerate(roofline['kernels']):
+            roofline['k%02d' % (i + 1)] = flat_row(r)[:118]
 
     # RCCL writes a version banner to the C-level stdout, which is block-buffered when piped and would
     # otherwise be flushed at exit, i.e. after the JSON line: push it out now on every rank, so that the JSON
     # is the last thing on stdout
     import ctypes
     ctypes.CDLL(None).fflush(None)
-    if dist.is_initialized():
-        dist.barrier()
+    runner.barrier()                                              # (gloo: works whatever the legs left behind)
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
-    os.dup2(saved_stdout_fd, 1)                                   # stdout is stdout again: the JSON line and nothing else
-    os.close(saved_stdout_fd)
+    deadline.cancel()
     if rank == 0:
-        bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM
-        total_bytes = bytes_per_launch * args.steps * n_gpus
-        value = total_bytes / elapsed / 1e9
-        kernel_us = event_ms * 1e3 / args.steps
-        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-        out = {
-            'metric': 'quantize_dequantize_GBps_64M_fp32_4bit',
-            'value': round(value, 2), 'unit': 'GB/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed * 1e3 / args.steps, 5), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {
-                'workload': 'quantization.uniformQuantization(x, s=16, type_of_scaling="linear", bucket_size=256), '
-                            'x = randn(64Mi) fp32 per GPU, deterministic rounding (BASELINE configs[1] hot path at the '
-                            "metric's headline size)",
-                'n_elements_per_gpu': N_ELEM, 'levels': LEVELS, 'bucket_size': BUCKET,
-                'algorithmic_bytes_per_element': ALGO_BYTES_PER_ELEM, 'rotating_buffers': N_ROTATE, 'precondition_launches': n_pre,
-                'parallelism': 'independent tensors per rank (no data-path collective)' if n_gpus > 1 else 'single GPU',
-            },
-            'roofline': {
-                'bound': 'hbm', 'kernel': 'k_bucket_vec<MODE_QDQ,16,4>',
-                'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBPS, 4),
-                'traffic': (traffic_measured or {}).get('bytes_per_launch') or load_pmc_traffic(),
-                'traffic_source': ('measured in this run (traffic_measured)' if (traffic_measured or {}).get('bytes_per_launch') else
-                                   'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on a '
-                                   'builder box (committed file, NOT measured in this run)'),
-                'traffic_measured': traffic_measured, 'traffic_committed': load_pmc_traffic(),
-                'extended': {'launches': ext_n, 'avg_launch_us': round(ext_us, 3),
-                             'frac': round(bytes_per_launch / (ext_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)},
-                'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
-                'timing': 'HIP events on the launch stream around the %d timed launches (includes inter-launch gaps)' % args.steps,
-                'torch_d2d_copy_GBps': round(copy_gbps, 1),      # torch's own copy of the same bytes, same box (a hand-written NT copy reaches 6.3-6.5 TB/s: profiles/r01_kbench.txt)
-            },
-            'cpu_baseline': cpu,
-            'distill': distill,
-            'parity_bit_exact_vs_oracle': parity,
-            'parity_bit_exact_vs_reference': parity_ref,
-            'rccl_world_size': rccl_world_size, 'rccl_error': rccl_error,
-            'device': torch.cuda.get_device_name(dev),
-        }
-        print(json.dumps(out), flush=True)
+        emit()
+    os.dup2(saved_stdout_fd, 1)                                   # stdout is stdout again
     if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+        runner.barrier()
+        if runner.broken is None:
+            dist.destroy_process_group()
+        else:
+            os._exit(0)                                           # a communicator with unmatched collectives cannot be torn down cleanly
 
 
 if __name__ == '__main__':

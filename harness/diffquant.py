@@ -61,8 +61,12 @@ class DiffQuantTrainer(object):
         for row, i in enumerate(self.slots):
             w = params[i].data
             self.points[row, :self.counts[row]] = qhf.initialize_quantization_points(w, scaling, self.counts[row])   # ref: :460-462
-            self.fns.append(quantization.nonUniformQuantization_variable(
-                bucket_size=bucket_size, pre_process_tensors=True, tensor=w))                  # ref: :507-509
+            if mode != 'multi':
+                # the reference's per-tensor objects (ref: :507-509); the multi-tensor path keeps its own resident u / alpha /
+                # beta (MultiTensorDiffQuant below) -- building both would hold a second copy of u (+331 MB on WRN-16-22)
+                # and run a second scale_down per tensor at setup
+                self.fns.append(quantization.nonUniformQuantization_variable(
+                    bucket_size=bucket_size, pre_process_tensors=True, tensor=w))
         self.points.grad = self.points_grad
         # identical replicas: the points (and the frozen weights they were initialised from) come from rank 0
         broadcast_from_rank0(self.points)

@@ -210,6 +210,18 @@ class DistillTrainer(object):
         shapes = {}
         for b in batches:
             shapes.setdefault(tuple(tuple(t.shape) for t in b), tuple(t.clone() for t in b))
+        # The warm-up below runs real steps -- it has to: MIOpen picks its plans, the optimizer creates its momentum buffers --
+        # but WITHOUT the gradient exchange, on the sample batches.  Training state must not see them: every rank would update
+        # its masters from its own un-reduced gradients and the replicas would stay apart for the rest of the run (only
+        # gradients are exchanged afterwards); a single rank would take warmup x #shapes hidden optimizer steps.  So the
+        # masters, the model's buffers (batch-norm statistics) and the optimizer state are put back afterwards; the momentum
+        # buffers the warm-up created stay allocated (the graph captures their addresses) and are zeroed, which is what a first
+        # optimizer step starts from.
+        had_state = {id(p): bool(self.opt.state.get(p)) for g in self.opt.param_groups for p in g['params']}
+        saved_master = self.flat_master.clone()
+        saved_buffers = [b.clone() for b in self.student.buffers()]
+        saved_momenta = {id(p): {k: v.clone() for k, v in self.opt.state[p].items() if torch.is_tensor(v)}
+                         for g in self.opt.param_groups for p in g['params'] if had_state[id(p)]}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -219,8 +231,18 @@ class DistillTrainer(object):
                     self.forward_backward(*sb)
                     self.clip()
                     self.opt.step()
+            with torch.no_grad():
+                self.flat_master.copy_(saved_master)
+                for b, v in zip(self.student.buffers(), saved_buffers):
+                    b.copy_(v)
+                for g in self.opt.param_groups:
+                    for p in g['params']:
+                        for k, v in self.opt.state[p].items():
+                            if torch.is_tensor(v):
+                                v.copy_(saved_momenta[id(p)][k]) if had_state[id(p)] else v.zero_()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        del saved_master, saved_buffers, saved_momenta
         self._graphs, pool = {}, None
         for key, sb in shapes.items():
             g = torch.cuda.CUDAGraph()

@@ -65,6 +65,7 @@ class GradSynchronizer(object):
         self.world = dist.get_world_size(group) if ready else 1
         force = force_collectives() if force is None else force
         self.active = ready and (self.world > 1 or force)
+        self.world_active = self.active      # `active` may be switched off and on between steps; this is what it returns to
         self._avg = bool(ready and dist.get_backend(group) == 'nccl')     # RCCL reduces to the mean itself
         n = flat_grad.numel()
         self.chunks = max(1, min(chunks, n))
@@ -94,6 +95,8 @@ class GradSynchronizer(object):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._ready(i))
 
     def _ready(self, i):
+        if not self.active:                  # switched off between steps (bench.py's step-without-exchange legs)
+            return
         if self._group_of is None:
             self._order.append(i)
             return

@@ -22,6 +22,9 @@
  *   - return value: 0 on success, a positive hipError_t if a launch failed, or a negative
  *     QD_ERR_* code for argument errors.  qd_error_string() describes either.
  *   - optional outputs may be NULL.
+ *   - alignment: fp32 data pointers need the 4 bytes of their type and nothing more (a tensor view that starts 4, 8 or
+ *     12 bytes into a 16-byte granule runs the same kernels at the same speed); int64 index outputs and workspaces 16
+ *     bytes, uint8 level / index outputs 4 bytes, unless an entry point says otherwise.
  *   - `mean`: optional device scalar subtracted from every element before anything else
  *     (subtract_mean=True, quant_functions.py:66-68) and added back at the end (:148).
  *   - `clamp`/`max_element`: if clamp != 0, values are clamped to [-max_element, max_element]
@@ -49,7 +52,11 @@ extern "C" {
 #define QD_STE_TIE_REFERENCE 0 /* first element at the top/bottom LEVEL of the quantized bucket */
 #define QD_STE_TIE_TRUE_ARG 1  /* true argmax/argmin of the input                               */
 
-/* Library identification: ABI version (bumped on incompatible changes) and target arch. */
+/* Library identification: ABI version (bumped on every change of an entry point's meaning or signature) and target arch.
+ * History: 1 = rounds 1-3; 2 = qd_nearest_point_f32 accepts q == NULL (indices only), qd_uniform_f32 accepts q == NULL with
+ * level_idx (levels only), qd_selftest_div_invariant, qd_digitize_histogram_f32 / qd_histogram_i64 added, 4-byte data alignment.
+ * The Python binding and _qd_glue.so compare the version THEY were built for with the library's. */
+#define QD_ABI_VERSION 2
 int qd_abi_version(void);
 const char* qd_target_arch(void);
 const char* qd_error_string(int code);
@@ -83,6 +90,9 @@ int qd_mean_f32(const float* x, int64_t n, float* mean_out, void* workspace, siz
  *     q = rint((x - beta)/alpha * (levels-1)) / (levels-1) * alpha + beta   [each op rounded]
  * x, q: [n] (q may alias x: modify_in_place).  alpha, beta: [num_buckets] optional outputs.
  * level_idx: optional [n] uint8 output of the integer level rint(u*(levels-1)) (levels <= 256).
+ * Levels only: q == NULL with level_idx given writes the levels (and alpha / beta if asked for) and nothing else -- 4 B read +
+ * 1 B written per element; deterministic rounding without mean / clamp, bucket in {64, 128, 256, 512, 1024, 2048}, x 16-byte
+ * aligned (the geometry of qd_pack_uniform_f32, whose 8-bit form this is); QD_ERR_UNSUPPORTED otherwise.
  * stochastic != 0 selects the stochastic-rounding branch (:174-187) with a counter-based
  * in-kernel generator keyed by (seed, element index).
  * workspace is only used when the tensor is a single bucket (bucket == 0 or n < bucket). */
@@ -122,7 +132,8 @@ int qd_bucket_argminmax_f32(const float* x, int64_t n, int64_t bucket, const flo
  * q: [n] = points[idx]*alpha + beta (+mean).  idx: optional, idx_bytes 8 (int64, what the
  * reference API returns) or 1 (uint8, k <= 256).
  * Indices only (what SearchSorted.query returns, :531-563): prescaled != 0 with q == NULL and idx given -- n >= 4,
- * buckets of at least 4 elements (or bucket == 0), x 16-byte aligned; QD_ERR_INVALID_ARGUMENT otherwise. */
+ * buckets of at least 4 elements (or bucket == 0), idx 16-byte (int64) / 4-byte (uint8) aligned; QD_ERR_INVALID_ARGUMENT
+ * otherwise. */
 int qd_nearest_point_f32(const float* x, int prescaled, const float* points, int k, int assign_mode, float* q,
                          void* idx, int idx_bytes, int64_t n, int64_t bucket, float* alpha, float* beta,
                          const float* mean, int clamp, float max_element, void* workspace, size_t workspace_bytes,
@@ -220,7 +231,7 @@ int qd_multi_point_grad_f32(const QdDiffQuantDesc* table, int ntensors, int64_t 
  * qd_pack_uniform_f32: quantize x with `levels` levels per bucket and store ONLY the level
  *   indices, `bits` (1, 2, 4 or 8; levels <= 2^bits) per element, element e in bits
  *   [e*bits, (e+1)*bits) of `packed` (qd_packed_bytes(n, bits) bytes, little endian inside a byte),
- *   plus alpha/beta [num_buckets].  bucket in {64,128,256,512,1024,2048}; x 16-byte aligned.
+ *   plus alpha/beta [num_buckets] (optional).  bucket in {64,128,256,512,1024,2048}; x 16-byte aligned.
  * qd_pack_levels_u8: the same packing for level indices that are already there (the level_idx output of qd_uniform_f32):
  *   together they give the packed form at ANY bucket size, bucket 0 = none included.
  * qd_unpack_uniform_f32: y = (index/(levels-1))*alpha + beta -- bit-identical to the output of
@@ -237,6 +248,19 @@ int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int 
 int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream);
 int qd_histogram_u8_ws(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* The two histograms get_huffman_encoding_mean_bit_length needs when it runs on the device (quantization/help_functions.py:
+ * 175-232; only the counters cross PCIe instead of every quantized tensor):
+ * qd_digitize_histogram_f32: hist[c] = #{ i : #{ j < m : edges[j] <= v[i] } == c }, c = 0 .. m (hist has m + 1 entries; a NaN
+ *   counts as c = m) -- np.digitize(v, edges) of :216-218 followed by np.unique(..., return_counts=True) of :223, for
+ *   `edges` a DEVICE array of m <= 256 increasing float64 values, compared in float64 as numpy does.  v: the re-scaled
+ *   quantized tensor (`scal.scale_down(q_tensor)`, :215), n elements, 4-byte aligned.
+ * qd_histogram_i64: hist[j] = #{ i : idx[i] == j } for j < k <= 256 and hist[k] = #{ i : idx[i] outside [0, k) } (k + 1
+ *   entries) -- the counts of the int64 indices nonUniformQuantization returns (:220-221).
+ * Both: workspace as for qd_histogram_u8_ws (required when n > 0), deterministic (per-block totals summed in a fixed order). */
+int qd_digitize_histogram_f32(const float* v, int64_t n, const double* edges, int m, uint64_t* hist, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int qd_histogram_i64(const int64_t* idx, int64_t n, int k, uint64_t* hist, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 /* ---- order statistics for initialize_quantization_points (quantization/help_functions.py:140-154: the reference
  * copies the scaled tensor to the host and calls np.percentile(a, linspace(0, 100, k)), which needs the two

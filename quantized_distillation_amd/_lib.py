@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, 'libqd_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 
+ABI_VERSION = 2                # QD_ABI_VERSION of include/qd_hip.h this file mirrors (tests/test_abi.py compares the two)
+
 _lib = None
 _lock = threading.Lock()
 
@@ -76,6 +78,8 @@ SIGNATURES = {
     'qd_unpack_uniform_f32': (c_int, [c_p, i64, i64, c_int, c_int, c_f, c_f, c_f, c_p]),
     'qd_histogram_u8': (c_int, [c_p, i64, c_int, c_p, c_p]),
     'qd_histogram_u8_ws': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),
+    'qd_digitize_histogram_f32': (c_int, [c_f, i64, c_p, c_int, c_p, c_p, c_size, c_p]),
+    'qd_histogram_i64': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),
     'qd_order_stats_workspace_bytes': (ctypes.c_size_t, [c_int]),
     'qd_order_stats_f32': (c_int, [c_p, i64, c_p, c_int, c_p, c_p, ctypes.c_size_t, c_p]),
     'qd_selftest_div_invariant': (c_int, [u64, i64, c_int, c_p, c_p]),
@@ -104,8 +108,9 @@ def load():
             fn = getattr(lib, name)          # AttributeError = ABI mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.qd_abi_version() != 1:
-            raise RuntimeError('libqd_hip.so ABI version %d, expected 1' % lib.qd_abi_version())
+        if lib.qd_abi_version() != ABI_VERSION:
+            raise RuntimeError('libqd_hip.so has ABI version %d, this binding is written for %d: rebuild it '
+                               '(python -c "import __graft_entry__ as g; g.build()")' % (lib.qd_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 
@@ -126,10 +131,17 @@ def glue():
                 'python -c "import __graft_entry__ as g; g.build()". There is no fallback binding.' % GLUE_PATH)
         import torch  # noqa: F401  (libtorch must be loaded before the extension)
         from . import _qd_glue
-        if _qd_glue.abi_version() != 1:
-            raise RuntimeError('_qd_glue.so is linked against ABI version %d, expected 1' % _qd_glue.abi_version())
+        if _qd_glue.abi_version() != ABI_VERSION:
+            raise RuntimeError('_qd_glue.so was compiled for ABI version %d, this binding and libqd_hip.so are at %d: rebuild it '
+                               '(python -c "import __graft_entry__ as g; g.build()")' % (_qd_glue.abi_version(), ABI_VERSION))
         _glue = _qd_glue
     return _glue
+
+
+def mark_written(tensors):
+    """A kernel launched through ctypes wrote over `tensors` (one tensor or a sequence): bump their version counters, as an
+    in-place torch op would have -- ScalingFunction's lazy arg indices and autograd's saved-tensor check rely on it."""
+    glue().mark_written(tensors)
 
 
 def check(code):

@@ -20,6 +20,19 @@ def hipcc():
     return exe
 
 
+def _headers():
+    """What every object / assembly file depends on besides its own source (ONE list for build_extension and
+    device_assembly: qd_transform.h holds almost all kernel code)."""
+    return [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.CSRC, 'qd_transform.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h'),
+            os.path.abspath(__file__)]
+
+
+def _tmp(path):
+    """Per-process temporary name next to `path`: concurrent first-import builds (N ranks under torchrun) must not write
+    the same file; each finishes with an atomic os.replace of a complete file."""
+    return '%s.tmp.%d' % (path, os.getpid())
+
+
 SOURCES = ['qd_kernels.hip', 'qd_nearest.hip', 'qd_reductions.hip', 'qd_scale.hip', 'qd_codec.hip', 'qd_multi_dq.hip', 'qd_abs.hip', 'qd_multi_global.hip',
            'qd_select.hip', 'qd_selftest.hip']
 OBJ_DIR = os.path.join(os.path.dirname(_lib.INCLUDE), 'build', 'obj')              # git-ignored; objects are rebuilt from source when stale
@@ -35,8 +48,7 @@ def build_extension(force=False, verbose=False, save_temps_dir=None):
     scratch / LDS metadata from it)."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(_lib.CSRC, f) for f in SOURCES]
-    hdrs = [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.CSRC, 'qd_transform.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h'),
-            os.path.abspath(__file__)]
+    hdrs = _headers()
     out = _lib.LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs = [os.path.join(OBJ_DIR, os.path.splitext(f)[0] + '.o') for f in SOURCES]
@@ -48,22 +60,24 @@ def build_extension(force=False, verbose=False, save_temps_dir=None):
         src, obj = pair
         if not stale(obj, [src] + hdrs):
             return
-        cmd = [hipcc()] + _compile_flags() + ['-c', src, '-o', obj + '.tmp']
+        tmp = _tmp(obj)
+        cmd = [hipcc()] + _compile_flags() + ['-c', src, '-o', tmp]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-        os.replace(obj + '.tmp', obj)
+        os.replace(tmp, obj)
 
     with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
     if save_temps_dir is not None:
         device_assembly(save_temps_dir, verbose=verbose)
     if stale(out, objs):
-        cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out + '.tmp']
+        tmp = _tmp(out)
+        cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', tmp]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-        os.replace(out + '.tmp', out)
+        os.replace(tmp, out)
     return out
 
 
@@ -72,18 +86,19 @@ def device_assembly(out_dir, verbose=False):
     newer than the sources."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(out_dir, exist_ok=True)
-    hdrs = [os.path.join(_lib.CSRC, 'qd_common.h'), os.path.join(_lib.INCLUDE, 'qd_hip.h'), os.path.abspath(__file__)]
+    hdrs = _headers()
 
     def one(f):
         src = os.path.join(_lib.CSRC, f)
         dst = os.path.join(out_dir, os.path.splitext(f)[0] + '.s')
         if os.path.exists(dst) and all(os.path.getmtime(dst) >= os.path.getmtime(d) for d in [src] + hdrs):
             return dst
-        cmd = [hipcc()] + [x for x in _compile_flags() if x != '-fPIC'] + ['-S', '--cuda-device-only', src, '-o', dst + '.tmp']
+        tmp = _tmp(dst)
+        cmd = [hipcc()] + [x for x in _compile_flags() if x != '-fPIC'] + ['-S', '--cuda-device-only', src, '-o', tmp]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-        os.replace(dst + '.tmp', dst)
+        os.replace(tmp, dst)
         return dst
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
@@ -109,14 +124,14 @@ def build_glue(force=False, verbose=False):
            '-D_GLIBCXX_USE_CXX11_ABI=%d' % int(torch._C._GLIBCXX_USE_CXX11_ABI),
            '-I', _lib.INCLUDE, '-I', os.path.join(tdir, 'include'),
            '-I', os.path.join(tdir, 'include', 'torch', 'csrc', 'api', 'include'), '-I', '/opt/rocm/include',
-           '-I', sysconfig.get_paths()['include'], src, '-o', out + '.tmp',
+           '-I', sysconfig.get_paths()['include'], src, '-o', _tmp(out),
            '-L', os.path.dirname(_lib.LIB_PATH), '-l:libqd_hip.so', '-L', os.path.join(tdir, 'lib'),
            '-ltorch_python', '-ltorch', '-ltorch_cpu', '-ltorch_hip', '-lc10', '-lc10_hip',
            '-Wl,-rpath,$ORIGIN', '-Wl,-rpath,' + os.path.join(tdir, 'lib')]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    os.replace(out + '.tmp', out)
+    os.replace(_tmp(out), out)
     return out
 
 

@@ -44,6 +44,7 @@ class PackedUniform(object):
 
 
 _FUSED_BUCKETS = (64, 128, 256, 512, 1024, 2048)
+QD_ERR_UNSUPPORTED = -3                 # include/qd_hip.h
 
 
 def pack_uniform(tensor, s, bucket_size=256, bits=None):
@@ -99,18 +100,28 @@ def histogram_u8(idx, k):
 
 
 def level_histogram(tensor, s, bucket_size=None):
-    """Histogram of the quantization levels of `tensor` (s <= 256), computed on the device: the
-    level index is a side output of the quantize kernel (1 B/element), then one counting pass."""
+    """Histogram of the quantization levels of `tensor` (s <= 256), computed on the device: the level indices are written by
+    the quantize kernel in its levels-only form (qd_uniform_f32 with q == NULL: 4 B read + 1 B written per element, no
+    throw-away q), then one counting pass (1 B read).  Bucket geometries outside that form (bucket_size None or not one of
+    64 ... 2048, a misaligned view) take the q-writing form of the same kernel."""
     _lib.require_device_f32(tensor)
     x = tensor.contiguous().view(-1)
+    if _lib.on_other_device(x):
+        with torch.cuda.device(x.device):
+            return level_histogram(tensor, s, bucket_size)
     n = x.numel()
     lev = torch.empty(n, dtype=torch.uint8, device=x.device)
-    q = torch.empty_like(x)
-    ws = _lib.workspace(x.device)
     if n > 0:
-        _lib.check(_lib.load().qd_uniform_f32(x.data_ptr(), q.data_ptr(), n, 0 if bucket_size is None else bucket_size,
-                                              int(s), None, None, lev.data_ptr(), None, 0, 0.0, 0, 0, ws.data_ptr(),
-                                              ws.numel(), _lib.stream_ptr()))
+        lib = _lib.load()
+        ws = _lib.workspace(x.device)
+        bucket = 0 if bucket_size is None else bucket_size
+        rc = lib.qd_uniform_f32(x.data_ptr(), None, n, bucket, int(s), None, None, lev.data_ptr(), None, 0, 0.0, 0, 0,
+                                ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        if rc == QD_ERR_UNSUPPORTED:
+            q = torch.empty_like(x)
+            rc = lib.qd_uniform_f32(x.data_ptr(), q.data_ptr(), n, bucket, int(s), None, None, lev.data_ptr(), None, 0, 0.0, 0, 0,
+                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc)
     return histogram_u8(lev, s)
 
 

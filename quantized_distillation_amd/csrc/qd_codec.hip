@@ -14,6 +14,7 @@
 #include "qd_common.h"
 
 #include <atomic>
+#include <type_traits>
 #include "../../include/qd_hip.h"
 
 using namespace qd;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void k_pack_vec(const float* x, uint8_t* packe
         if (group_any<LPB>(nan)) { mn = NAN; mx = NAN; }   // a NaN bucket has NaN alpha/beta (its indices are meaningless)
         float a, b;
         alpha_beta(mn, mx, a, b);
-        if (l == 0) { alpha[bkt] = a; beta[bkt] = b; }
+        if (l == 0) { if (alpha) alpha[bkt] = a; if (beta) beta[bkt] = b; }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int64_t e = e0 + (int64_t)j * LPB * 4;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64) void k_pack_tail(const float* x, uint8_t* packe
     if (group_any<64>(nan)) { mn = NAN; mx = NAN; }
     float a, b;
     alpha_beta(mn, mx, a, b);
-    if (lane == 0) { alpha[bkt] = a; beta[bkt] = b; }
+    if (lane == 0) { if (alpha) alpha[bkt] = a; if (beta) beta[bkt] = b; }
     constexpr int EPB = 8 / BITS;                    // elements per byte
     const int64_t first_byte = (lo * BITS) >> 3;     // lo is a multiple of the bucket (>= 64)
     const int64_t nbytes = (((n - lo) * BITS) + 7) >> 3;
@@ -339,6 +340,90 @@ __global__ __launch_bounds__(256) void k_hist_fold(const unsigned long long* par
     if (threadIdx.x == 0) hist[j] = (accumulate ? hist[j] : 0ull) + wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// Histograms of symbols that are COMPUTED from wider elements, for the Huffman accounting of quantization/help_functions.py:
+// 175-232 run on the device:
+//   SRC_DIGITIZE  fp32 values v -> c = #{ j < m : edges[j] <= v } in 0..m, NaN -> m: np.digitize(v, edges) for increasing
+//                 float64 edges, compared in float64 as numpy does after promoting the float32 data (:216-218);
+//   SRC_I64       int64 symbols (the indices nonUniformQuantization returns, :220-221); anything outside [0, nrows - 1) is
+//                 counted in the LAST row, so the caller can tell that the table was too small.
+// Same counting scheme as k_hist_atomic ([nrows][32] uint32 in LDS, integer atomics, column = lane mod 32) without its
+// software pipeline: 4 / 8 bytes per symbol instead of 1, so the HBM stream, not the LDS atomics, is what bounds it.
+// Per-block totals go to partial[row][block]; k_hist_fold sums them.
+enum { SRC_DIGITIZE = 0, SRC_I64 = 1 };
+
+__device__ __forceinline__ uint32_t digitize_count(const double* edges, int m, double e0, double inv, float v) {
+    if (v != v) return (uint32_t)m;                        // NaN sorts last (numpy's searchsorted)
+    const double x = (double)v;
+    // candidate from the mean spacing (exact for evenly spaced edges up to rounding), then walked to the exact place:
+    // g = largest index with edges[g] <= x, or -1
+    const double t = (x - e0) * inv;
+    int g = t < 0.0 ? -1 : (t >= (double)(m - 1) ? m - 1 : (int)t);
+    while (g + 1 < m && edges[g + 1] <= x) ++g;
+    while (g >= 0 && edges[g] > x) --g;
+    return (uint32_t)(g + 1);
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_hist_sym(const void* data, int64_t n, int nrows, const double* edges_g, int m,
+                                                  unsigned long long* partial /* [nrows][gridDim.x] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hist_lds[];
+    double* edges = (double*)hist_lds;                                        // [m] (SRC_DIGITIZE), 8-byte aligned
+    uint32_t* cnt = (uint32_t*)(hist_lds + (SRC == SRC_DIGITIZE ? (size_t)((m + 1) & ~1) * sizeof(double) : 0));   // [nrows][32]
+    typedef typename std::conditional<SRC == SRC_DIGITIZE, float, long long>::type T;
+    constexpr int E = 16 / (int)sizeof(T);                                    // symbols per 16-byte load
+    const T* src = (const T*)data;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * 256;
+    for (int j = threadIdx.x; j < nrows * 32; j += 256) cnt[j] = 0;
+    if (SRC == SRC_DIGITIZE)
+        for (int j = threadIdx.x; j < m; j += 256) edges[j] = edges_g[j];
+    __syncthreads();
+    double e0 = 0.0, inv = 0.0;
+    if (SRC == SRC_DIGITIZE) {
+        e0 = edges[0];
+        const double span = edges[m - 1] - e0;
+        inv = (m > 1 && span > 0.0) ? (double)(m - 1) / span : 0.0;
+    }
+    uint32_t* col = cnt + (threadIdx.x & 31);
+    const uint32_t last = (uint32_t)(nrows - 1);
+    auto bump = [&](T v) {
+        uint32_t sy;
+        if constexpr (SRC == SRC_DIGITIZE) sy = digitize_count(edges, m, e0, inv, v);
+        else sy = (v < 0 || v >= (long long)last) ? last : (uint32_t)v;
+        __hip_atomic_fetch_add(col + (sy < last ? sy : last) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    int64_t head = (int64_t)(((16 - (((uintptr_t)src) & 15)) & 15) / sizeof(T));   // elements before the first 16-byte boundary
+    if (head > n) head = n;
+    for (int64_t i = tid; i < head; i += nth) bump(src[i]);
+    const int64_t nvec = (n - head) / E;
+    typedef T vecT __attribute__((ext_vector_type(E)));
+    const vecT* body = (const vecT*)(src + head);
+    constexpr int U = 4;                                                      // loads in flight per lane
+    int64_t i = tid;
+    for (; i + (int64_t)(U - 1) * nth < nvec; i += (int64_t)U * nth) {
+        vecT w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(body + i + (int64_t)u * nth);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < E; ++c) bump(w[u][c]);
+    }
+    for (; i < nvec; i += nth) {
+        const vecT w = __builtin_nontemporal_load(body + i);
+#pragma unroll
+        for (int c = 0; c < E; ++c) bump(w[c]);
+    }
+    for (int64_t t = head + nvec * E + tid; t < n; t += nth) bump(src[t]);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nrows; j += 256) {
+        unsigned long long total = 0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) total += cnt[j * 32 + ((c + j) & 31)];
+        partial[(size_t)j * gridDim.x + blockIdx.x] = total;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_zero_u64(unsigned long long* p, int n) {
     for (int i = threadIdx.x; i < n; i += 256) p[i] = 0ull;
 }
@@ -359,7 +444,7 @@ int qd_pack_uniform_f32(const float* x, int64_t n, int64_t bucket, int levels, i
                         float* beta, void* stream) {
     if (n < 0 || levels < 2 || (bits != 1 && bits != 2 && bits != 4 && bits != 8) || levels > (1 << bits))
         return QD_ERR_INVALID_ARGUMENT;
-    if (n > 0 && (!x || !packed || !alpha || !beta)) return QD_ERR_INVALID_ARGUMENT;
+    if (n > 0 && (!x || !packed)) return QD_ERR_INVALID_ARGUMENT;      // alpha / beta: optional outputs
     if (bucket != 64 && bucket != 128 && bucket != 256 && bucket != 512 && bucket != 1024 && bucket != 2048)
         return QD_ERR_UNSUPPORTED;                       // the codec is defined for the vector bucket sizes
     if ((((uintptr_t)x) & 15) || (((uintptr_t)packed) & 3)) return QD_ERR_UNSUPPORTED;
@@ -446,10 +531,7 @@ int qd_histogram_u8_ws(const uint8_t* idx, int64_t n, int k, uint64_t* hist, voi
                        void* stream) {
     if (n < 0 || k < 1 || k > 256 || !hist || (n > 0 && !idx)) return QD_ERR_INVALID_ARGUMENT;
     hipStream_t st = (hipStream_t)stream;
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
+    const int cus = device_cus();
     const size_t lds = (size_t)(k + 1) * 32 * sizeof(uint32_t);
     // Measured at 64 Mi symbols (tools/tune_r2.py, profiles/r02_tune_kernels.txt).  Private-column tables with the four
     // symbols of a word merged in registers (round 1 / early round 2): 35 us (k <= 64), 49 us (k = 256); register counters
@@ -488,6 +570,52 @@ int qd_histogram_u8_ws(const uint8_t* idx, int64_t n, int k, uint64_t* hist, voi
                            (unsigned long long*)nullptr);
     }
     return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+namespace {
+template <int SRC>
+int launch_hist_sym(const void* data, int64_t n, int nrows, const double* edges, int m, uint64_t* hist, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_zero_u64, dim3(1), dim3(256), 0, st, (unsigned long long*)hist, nrows);
+        return (int)hipGetLastError();
+    }
+    if (!workspace || (((uintptr_t)workspace) & 7)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    const int cus = device_cus();
+    int blocks = blocks_for(n, 256 * 16, cus * 4);
+    const size_t room = workspace_bytes / ((size_t)nrows * sizeof(unsigned long long));
+    if ((size_t)blocks > room) blocks = (int)room;
+    if (blocks < 1) return QD_ERR_WORKSPACE_TOO_SMALL;
+    const size_t lds = (size_t)nrows * 32 * sizeof(uint32_t) + (SRC == SRC_DIGITIZE ? (size_t)((m + 1) & ~1) * sizeof(double) : 0);
+    const int64_t slice = (int64_t)blocks << 31;               // a uint32 counter holds what ONE block counts in one launch
+    const size_t esz = SRC == SRC_DIGITIZE ? sizeof(float) : sizeof(long long);
+    for (int64_t off = 0; off < n; off += slice) {
+        const int64_t len = n - off < slice ? n - off : slice;
+        hipLaunchKernelGGL((k_hist_sym<SRC>), dim3(blocks), dim3(256), lds, st, (const void*)((const char*)data + off * esz), len, nrows,
+                           edges, m, (unsigned long long*)workspace);
+        hipLaunchKernelGGL(k_hist_fold, dim3(nrows), dim3(256), 0, st, (const unsigned long long*)workspace, blocks,
+                           (unsigned long long*)hist, off > 0 ? 1 : 0);
+    }
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" {
+
+int qd_digitize_histogram_f32(const float* v, int64_t n, const double* edges, int m, uint64_t* hist, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (n < 0 || m < 1 || m > 256 || !edges || !hist || (n > 0 && !v)) return QD_ERR_INVALID_ARGUMENT;
+    if ((((uintptr_t)v) & 3) || (((uintptr_t)edges) & 7)) return QD_ERR_INVALID_ARGUMENT;
+    return launch_hist_sym<SRC_DIGITIZE>(v, n, m + 1, edges, m, hist, workspace, workspace_bytes, stream);
+}
+
+int qd_histogram_i64(const int64_t* idx, int64_t n, int k, uint64_t* hist, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || k < 1 || k > 256 || !hist || (n > 0 && !idx)) return QD_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)idx) & 7) return QD_ERR_INVALID_ARGUMENT;
+    return launch_hist_sym<SRC_I64>(idx, n, k + 1, nullptr, 0, hist, workspace, workspace_bytes, stream);
 }
 
 int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream) {

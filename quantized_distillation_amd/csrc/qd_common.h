@@ -32,7 +32,12 @@ template <typename T> __device__ __forceinline__ void stg_nt(const T& v, T* p) {
 // 85 us).  tests/test_abi.py checks the shipped code objects for that.  The s_nop is the wait state the hardware needs
 // between a store of more than 8 bytes and a VALU write of its data registers: the hazard recogniser does not look inside
 // an asm block (without it a golden case stored a register the next instruction had already overwritten).
-__device__ __forceinline__ void store_nt_pinned(f4* p, const f4& v) {
+// The instruction is a GLOBAL store, so the pointer type says so (address space 1: a generic pointer into LDS or scratch
+// does not convert implicitly), and the wait-state count is gfx950's: this header is for that target only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "qd_common.h: hand-written gfx950 ISA (store_nt_pinned's wait states, DPP controls): compile with --offload-arch=gfx950"
+#endif
+__device__ __forceinline__ void store_nt_pinned(QD_AS_GLOBAL f4* p, const f4& v) {
     asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 template <typename T> __device__ __forceinline__ T ldg(const T* p) { return *(const QD_AS_GLOBAL T*)p; }
@@ -40,6 +45,21 @@ template <typename T> __device__ __forceinline__ void stg(const T& v, T* p) { *(
 // wave index within the grid as a scalar (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
 __device__ __forceinline__ int64_t uniform_wave_index() {
     return (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+// ---- compute units of the CURRENT device (256 on MI355X), cached per device ----
+// (one process may drive several devices: the API takes tensors of any device and launches with that device current)
+inline int device_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    const int slot = dev & 63;
+    int v = __atomic_load_n(&cache[slot], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        if (dev < 64) __atomic_store_n(&cache[slot], v, __ATOMIC_RELAXED);
+    }
+    return v;
 }
 
 // ---- NaN-propagating min / max ----

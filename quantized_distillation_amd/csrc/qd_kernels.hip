@@ -27,7 +27,7 @@ extern "C" int qd_fused_mode_state = 1;       // see qd_transform.h
 // ================================ C ABI ========================================================
 extern "C" {
 
-int qd_abi_version(void) { return 1; }
+int qd_abi_version(void) { return QD_ABI_VERSION; }
 
 int qd_set_single_fused_mode(int mode) {
     const int prev = qd_fused_mode_state;
@@ -62,8 +62,17 @@ int64_t qd_padded_length(int64_t n, int64_t bucket) {
 int qd_uniform_f32(const float* x, float* q, int64_t n, int64_t bucket, int levels, float* alpha, float* beta,
                    uint8_t* level_idx, const float* mean, int clamp, float max_element, int stochastic,
                    uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
-    if (n < 0 || levels < 2 || bucket < 0 || (n > 0 && (!x || !q))) return QD_ERR_INVALID_ARGUMENT;
+    if (n < 0 || levels < 2 || bucket < 0 || (n > 0 && !x)) return QD_ERR_INVALID_ARGUMENT;
     if (level_idx && levels > 256) return QD_ERR_INVALID_ARGUMENT;
+    if (n > 0 && !q) {
+        // levels only: the integer level of every element (1 B written per element instead of 4 + 1) -- what the Huffman
+        // accounting and the packed codec consume.  That is the fused pack kernel with 8 bits per level (qd_codec.hip), so
+        // its geometry applies: deterministic rounding, no mean / clamp, bucket in {64 ... 2048}, x 16-byte aligned;
+        // QD_ERR_UNSUPPORTED otherwise (callers then take the q-writing form).
+        if (!level_idx) return QD_ERR_INVALID_ARGUMENT;
+        if (stochastic || mean || clamp) return QD_ERR_UNSUPPORTED;
+        return qd_pack_uniform_f32(x, n, bucket, levels, 8, level_idx, alpha, beta, stream);
+    }
     KParams p = {};
     p.x = x; p.out = q; p.n = n; p.alpha = alpha; p.beta = beta; p.mean = mean;
     p.me = clamp ? max_element : INFINITY;

@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
                 if (base + 2 == jmax) o.z = o.z + sum;  if (base + 2 == jmin) o.z = o.z - sum;
                 if (base + 3 == jmax) o.w = o.w + sum;  if (base + 3 == jmin) o.w = o.w - sum;
             }
-            if (V == 1) store_nt_pinned((f4*)(out + e0) + j * LPB, o);      // (the V = 1 instance loses the hint otherwise)
+            if (V == 1) store_nt_pinned((QD_AS_GLOBAL f4*)(out + e0) + j * LPB, o);      // (the V = 1 instance loses the hint otherwise)
             else __builtin_nontemporal_store(o, (f4*)(out + e0) + j * LPB);
         }
     }

@@ -324,10 +324,9 @@ int qd_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int m, f
     uint32_t* prefix_b = (uint32_t*)(ws + l.prefix_b);
     uint32_t* resid = (uint32_t*)(ws + l.resid);
 
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = MAX_BLOCKS;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    const int cus = device_cus();
     constexpr int U = 4;
     int64_t want = (n + (int64_t)SEL_THREADS * 4 * U - 1) / ((int64_t)SEL_THREADS * 4 * U);
     const int cap = cus < MAX_BLOCKS ? cus : MAX_BLOCKS;

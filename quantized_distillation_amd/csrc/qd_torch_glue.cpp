@@ -75,6 +75,14 @@ const at::Tensor& tensor_arg(PyObject* o, const char* what) {
     return THPVariable_Unpack(o);
 }
 
+// A kernel has written over `t` through its raw pointer: tell torch.  The version counter is what
+// ScalingFunction's lazily computed arg-min/max indices check before they trust a retained tensor (quant_functions.py:
+// _compute_arg_indices) and what autograd checks on tensors saved for backward; views share the counter of their base.
+// (Inference tensors carry no counter and cannot be written in place outside inference mode.)
+inline void mark_written(const at::Tensor& t) {
+    if (t.defined() && !t.is_inference()) t.unsafeGetTensorImpl()->bump_version();
+}
+
 void require_device_f32(const at::Tensor& t, const char* what) {
     if (!t.is_cuda())
         throw std::runtime_error(std::string("quantized_distillation_amd: ") + what +
@@ -142,6 +150,7 @@ PyObject* glue_uniform(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
         check_rc(qd_uniform_f32(x.data_ptr<float>(), q.data_ptr<float>(), n, bucket, static_cast<int>(levels), abp, abp + nb,
                                 nullptr, mean_ptr, clamp, static_cast<float>(max_element), stochastic, seed,
                                 nb == 1 ? ws : nullptr, nb == 1 ? ws_bytes : 0, stream));
+        if (in_place) mark_written(x);
     } else {                                               // nothing to scale: defined values, not uninitialised memory
         ab.zero_();
         if (subtract_mean) {
@@ -371,6 +380,7 @@ PyObject* glue_nearest(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
                                       static_cast<int>(assign_mode), q.data_ptr<float>(), idx.data_ptr(),
                                       static_cast<int>(idx_bytes), n, bucket, alpha.data_ptr<float>(), beta.data_ptr<float>(),
                                       mean_ptr, clamp, static_cast<float>(max_element), ws, ws_bytes, stream));
+        if (in_place) mark_written(x);
     }
     PyObject* out = PyTuple_New(2);
     PyTuple_SET_ITEM(out, 0, THPVariable_Wrap(q));
@@ -413,7 +423,9 @@ PyObject* glue_point_grad(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     END_HANDLE_TH_ERRORS
 }
 
-PyObject* glue_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(qd_abi_version()); }
+// the version of include/qd_hip.h THIS module was compiled against (a stale _qd_glue.so next to a newer libqd_hip.so, or the
+// other way round, must not pass: _lib.glue() compares it with the library's qd_abi_version())
+PyObject* glue_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(QD_ABI_VERSION); }
 
 // host_cost_probe(x, levels, bucket, iters) -> (us per bare C-ABI launch, us per output allocation pair, us per launch with
 // allocation).  Measurement aid for tools/profile_api_overhead.py: where the per-call host time of uniform() goes.
@@ -471,7 +483,33 @@ PyObject* glue_host_cost_probe(PyObject*, PyObject* const* args, Py_ssize_t narg
     END_HANDLE_TH_ERRORS
 }
 
+// mark_written(t | sequence of tensors): for the entry points bound with ctypes (in-place scale_down / inv_scale_down, the
+// STE kernels, the multi-tensor launches), whose outputs torch has not seen being written.
+PyObject* glue_mark_written(PyObject*, PyObject* arg) {
+    HANDLE_TH_ERRORS
+    if (THPVariable_Check(arg)) {
+        mark_written(THPVariable_Unpack(arg));
+    } else {
+        PyObject* seq = PySequence_Fast(arg, "mark_written() takes a tensor or a sequence of tensors");
+        if (!seq) return nullptr;
+        const Py_ssize_t m = PySequence_Fast_GET_SIZE(seq);
+        for (Py_ssize_t i = 0; i < m; ++i) {
+            PyObject* o = PySequence_Fast_GET_ITEM(seq, i);
+            if (!THPVariable_Check(o)) {
+                Py_DECREF(seq);
+                PyErr_SetString(PyExc_TypeError, "mark_written() takes a tensor or a sequence of tensors");
+                return nullptr;
+            }
+            mark_written(THPVariable_Unpack(o));
+        }
+        Py_DECREF(seq);
+    }
+    Py_RETURN_NONE;
+    END_HANDLE_TH_ERRORS
+}
+
 PyMethodDef methods[] = {
+    {"mark_written", glue_mark_written, METH_O, "mark_written(tensor | [tensors]): bump the version counter of tensors a kernel wrote through raw pointers"},
     {"uniform", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_uniform)), METH_FASTCALL,
      "uniform(x, levels, bucket, clamp, max_element, stochastic, seed, subtract_mean, in_place) -> (q, ab, mean, n, x_read)"},
     {"uniform_common", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_uniform_common)), METH_FASTCALL,
@@ -483,7 +521,7 @@ PyMethodDef methods[] = {
      "point_grad(g, idx, alpha, bucket, k) -> grad_points"},
     {"host_cost_probe", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(glue_host_cost_probe)), METH_FASTCALL,
      "host_cost_probe(x, levels, bucket, iters) -> (launch us, allocation us, both us): host time per call"},
-    {"abi_version", glue_abi_version, METH_NOARGS, "ABI version of the libqd_hip.so this module is linked against"},
+    {"abi_version", glue_abi_version, METH_NOARGS, "QD_ABI_VERSION of the include/qd_hip.h this module was compiled against"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_qd_glue",

@@ -616,7 +616,7 @@ __device__ __forceinline__ void vec_apply(const KParams& p, const PointTable* T,
         }
         // MODE_SCALE: the whole-tile and partial-tile copies of this loop are merged by the compiler, and the merged store
         // loses its !nontemporal flag (qd_common.h store_nt_pinned)
-        if (MODE == MODE_SCALE) store_nt_pinned(dst + j * LPB, r);
+        if (MODE == MODE_SCALE) store_nt_pinned((QD_AS_GLOBAL f4*)dst + j * LPB, r);
         else __builtin_nontemporal_store(r, dst + j * LPB);
         store_side4_row<MODE>(p, e, side);
     }
@@ -1699,19 +1699,8 @@ inline void geometry(int64_t n, int64_t bucket, int64_t& nb, int64_t& row) {
     nb = (n + bucket - 1) / bucket;
 }
 
-// compute units of the current device (256 on MI355X); queried once per process
-inline int num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-        else
-            cus = 256;
-    }
-    return cus;
-}
+// compute units of the current device (256 on MI355X), cached PER DEVICE (qd_common.h)
+inline int num_cus() { return device_cus(); }
 
 inline int grid_cap() {
     // Measured on MI355X (tools/tune_k1.py, profiles/r01_tune.txt): one wave-tile per wave (no grid-stride
@@ -1916,7 +1905,11 @@ constexpr int kNotFused = -1000;
 // (the switch itself lives in qd_kernels.hip -- one variable for the three translation units that include this header)
 template <int MODE, int V, int W>
 int fused_capacity() {                                         // blocks of k_single_fused<MODE, V> resident at once, 0 if unusable
-    static int cap = -1;
+    static int caps[64];                                       // per device, stored + 1 (0 = not asked yet)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int& slot = caps[dev & 63];
+    int cap = __atomic_load_n(&slot, __ATOMIC_RELAXED) - 1;
     if (cap < 0) {
         int per_cu = 0;
         hipFuncAttributes fa;
@@ -1927,6 +1920,7 @@ int fused_capacity() {                                         // blocks of k_si
         (void)hipGetLastError();
         int c = per_cu * num_cus();
         cap = c > kFusedMaxBlocks ? kFusedMaxBlocks : c;
+        if (dev < 64) __atomic_store_n(&slot, cap + 1, __ATOMIC_RELAXED);
     }
     return cap;
 }

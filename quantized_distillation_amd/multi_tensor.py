@@ -87,6 +87,7 @@ class MultiTensorQuantizer(object):
         else:
             _lib.check(_lib.load().qd_multi_uniform_f32(self._table.data_ptr(), len(self.inputs), self._tiles,
                                                         self.bucket_size, self.s, _lib.stream_ptr(self.device)))
+        _lib.mark_written(self.outputs)          # written through the device table: one native call bumps their version counters
         return self.outputs
 
 
@@ -186,6 +187,7 @@ class MultiTensorDiffQuant(object):
         self._check()
         _lib.check(_lib.load().qd_multi_nearest_f32(self._table.data_ptr(), self.n_tensors, self._tiles, self.bucket_size,
                                                     points.data_ptr(), self.k, _lib.stream_ptr(self.device)))
+        _lib.mark_written(self.outputs)
         return self.outputs
 
     def backward(self, out=None):

@@ -197,10 +197,51 @@ def huffman_encode(symb2freq):
     return sorted(heappop(heap)[1:], key=lambda e: (len(e[-1]), e))
 
 
+DEVICE_HISTOGRAM_MAX_SYMBOLS = 256      # the LDS tables of qd_digitize_histogram_f32 / qd_histogram_i64 hold this many
+
+
+def _digitize_edges(s, tol):
+    """The bin edges the reference digitizes against, built exactly as it builds them (ref: :213-216): Python floats."""
+    return np.array([x / (s - 1) - tol for x in range(s)], dtype=np.float64)
+
+
+def _device_counts(kind, values, nsym, edges_dev=None):
+    """int64 device tensor of nsym + 1 counters (include/qd_hip.h: qd_digitize_histogram_f32 / qd_histogram_i64) of a flat,
+    contiguous device tensor, or None when this tensor cannot take the device path (host fallback)."""
+    from .. import _lib
+    if not isinstance(values, torch.Tensor) or not values.is_cuda or nsym > DEVICE_HISTOGRAM_MAX_SYMBOLS:
+        return None
+    if kind == 'digitize' and values.dtype != torch.float32:
+        return None
+    if kind == 'index' and values.dtype != torch.int64:
+        return None
+    values = values.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(values.device):
+        hist = torch.empty(nsym + 1, dtype=torch.int64, device=values.device)
+        ws = _lib.workspace(values.device)
+        if kind == 'digitize':
+            rc = lib.qd_digitize_histogram_f32(values.data_ptr(), values.numel(), edges_dev.data_ptr(), nsym, hist.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr(values.device))
+        else:
+            rc = lib.qd_histogram_i64(values.data_ptr(), values.numel(), nsym, hist.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _lib.stream_ptr(values.device))
+    _lib.check(rc)
+    return hist
+
+
 def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_functions, type_quantization='uniform',
                                          s=None):
     """Mean Huffman code length (bits/weight) of the quantization indices of a model.
-    ref: help_functions.py:175-232."""
+    ref: help_functions.py:175-232.
+
+    Same steps as the reference for every tensor -- call the quantization function, re-scale the quantized tensor with the
+    scaling function it returned, digitize against the s level positions (uniform) or take the returned indices
+    (non-uniform), count the symbols -- but the counting runs on the device: the reference copies every quantized tensor
+    to the host for np.digitize + np.unique (:215-223); here the digitize + histogram is one kernel over the re-scaled
+    tensor (qd_digitize_histogram_f32, same float64 comparison against the same edges) or over the int64 indices
+    (qd_histogram_i64), and only the s + 1 (k + 1) counters cross PCIe.  Tensors that cannot take that path (more than 256
+    symbols, or a quantization function that returns host tensors) are counted on the host exactly as before."""
     type_quantization = type_quantization.lower()
     if type_quantization not in ('uniform', 'nonuniform'):
         raise ValueError('type_quantization not recognized')
@@ -212,6 +253,13 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
     counts = defaultdict(int)
     total = 0
     tol = 1e-5
+    edges = _digitize_edges(s, tol) if type_quantization == 'uniform' else None
+    edges_dev, device_totals = {}, {}           # per device: the edges, the running int64 counters (uniform)
+
+    def host_count(bins):
+        for value, count in zip(*np.unique(bins, return_counts=True)):
+            counts[value] += count
+
     for pos, param in enumerate(model_param_iter):
         param = param.clone()
         if hasattr(param, 'data'):
@@ -220,14 +268,29 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
         fn = quantization_functions[0] if shared else quantization_functions[pos]
         if type_quantization == 'uniform':
             q_tensor, scal = fn(param)
-            scaled = scal.scale_down(q_tensor).view(-1)[0:scal.original_tensor_length].cpu().numpy()
-            edges = [x / (s - 1) - tol for x in range(s)]
-            bins = np.digitize(scaled, edges).flatten() - 1
+            scaled = scal.scale_down(q_tensor).view(-1)[0:scal.original_tensor_length]
+            dev = scaled.device if isinstance(scaled, torch.Tensor) else None
+            if dev is not None and dev.type == 'cuda' and dev not in edges_dev:
+                edges_dev[dev] = torch.from_numpy(edges).to(dev)
+            hist = _device_counts('digitize', scaled, s, edges_dev.get(dev))
+            if hist is not None:                             # hist[c] = #{digitize == c}; the reference's bin is c - 1
+                device_totals[dev] = hist if dev not in device_totals else device_totals[dev] + hist
+            else:
+                host_count(np.digitize(scaled.cpu().numpy(), edges).flatten() - 1)
         else:
             _, bins, _ = fn(param)
-            bins = bins.view(-1).cpu().numpy()
-        for value, count in zip(*np.unique(bins, return_counts=True)):
-            counts[value] += count
+            bins = bins.view(-1)
+            hist = _device_counts('index', bins, DEVICE_HISTOGRAM_MAX_SYMBOLS)
+            h = hist.cpu().numpy() if hist is not None else None
+            if h is not None and h[-1] == 0:                 # (last counter: indices outside the table -- then count on the host)
+                for value in np.nonzero(h[:-1])[0]:
+                    counts[int(value)] += int(h[value])
+            else:
+                host_count(bins.cpu().numpy())
+    for hist in device_totals.values():
+        h = hist.cpu().numpy()
+        for c in np.nonzero(h)[0]:
+            counts[int(c) - 1] += int(h[c])
     assert total == sum(counts.values())
     freq = {sym: c / total for sym, c in counts.items()}
     return sum(freq[sym] * len(code) for sym, code in huffman_encode(freq))

@@ -293,6 +293,8 @@ class ScalingFunction(object):
             _lib.check(_lib.load().qd_scale_down_f32(
                 tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(self.bucket_size), ab[0].data_ptr(),
                 ab[1].data_ptr(), _ptr(self._mean_buf), clamp, me, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+            if in_place:
+                _lib.mark_written(tensor)          # the kernel wrote over the input through its raw pointer
         return out.view(self.expected_tensor_size)
 
     def _scale_down_abs(self, tensor, n, nb, padded):
@@ -337,6 +339,8 @@ class ScalingFunction(object):
             _lib.check(_lib.load().qd_inv_scale_f32(
                 tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(self.bucket_size), self.alpha.data_ptr(),
                 self.beta.data_ptr(), _ptr(self._mean_buf), _lib.stream_ptr()))
+            if self.modify_in_place:
+                _lib.mark_written(tensor)
         return out.view(self.original_tensor_size)
 
 
@@ -450,6 +454,8 @@ def _uniform_abs(tensor, s, scaling_function, stochastic_rounding, modify_in_pla
             tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(bucket_size), int(s), scaling_function._abs_kind(),
             norm.data_ptr(), _ptr(scaling_function._mean_buf), clamp, me, ws.data_ptr(), ws.numel(),
             _lib.stream_ptr(tensor.device)))
+        if modify_in_place:
+            _lib.mark_written(tensor)
     scaling_function.norm_scaling = norm.view(1) if bucket_size is None else norm.view(nb, 1)
     return out, scaling_function
 

@@ -25,6 +25,7 @@ def clamp_(weights, limit=1.0):
     if w.numel():
         with torch.cuda.device(w.device):
             _lib.check(_lib.load().qd_clamp_f32(w.data_ptr(), w.numel(), float(limit), _lib.stream_ptr(w.device)))
+        _lib.mark_written(w)               # written through its raw pointer: bump the version counter as clamp_() would
     return weights
 
 
@@ -37,6 +38,7 @@ def truncated_ste_(grad, weights, limit=1.0):
         with torch.cuda.device(g.device):
             _lib.check(_lib.load().qd_truncated_ste_f32(w.data_ptr(), g.data_ptr(), g.numel(), float(limit),
                                                         _lib.stream_ptr(g.device)))
+        _lib.mark_written(g)
     return grad
 
 
@@ -50,6 +52,7 @@ def ste_bucket_backward(weights, grad, bucket_size, s, out=None, tie_mode='refer
     if bucket_size is None:                                                         # ref: :332-334
         raise NotImplementedError('Right now the code does not work with bucket_size None.'
                                   ' Not hard to modify though')
+    given = out is not None
     if out is None:
         out = torch.empty_like(g)
     else:
@@ -61,4 +64,6 @@ def ste_bucket_backward(weights, grad, bucket_size, s, out=None, tie_mode='refer
             _lib.check(_lib.load().qd_ste_bucket_backward_f32(
                 x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel(), int(bucket_size), int(s),
                 0 if tie_mode == 'reference' else 1, _lib.stream_ptr(x.device)))
+        if given:
+            _lib.mark_written(out)
     return out

@@ -39,7 +39,9 @@ def test_exports_match_header(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.qd_abi_version() == 1
+    # one number in three places: the header's QD_ABI_VERSION (what the library and _qd_glue.so compile in) and the Python binding's
+    header = open(os.path.join(ROOT, 'include', 'qd_hip.h')).read()
+    assert int(re.search(r'#define QD_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == lib.qd_abi_version() == 2
     assert lib.qd_target_arch() == b'gfx950'
     assert lib.qd_workspace_bytes() >= 64 * 1024
     assert lib.qd_error_string(0) == b'success'
@@ -99,8 +101,8 @@ def test_native_glue_loads_and_fails_loudly_on_cpu_tensors():
     import torch
     from quantized_distillation_amd import _lib
     g = _lib.glue()
-    assert g.abi_version() == _lib.load().qd_abi_version() == 1
-    for name in ('uniform', 'nearest', 'point_grad'):
+    assert g.abi_version() == _lib.load().qd_abi_version() == _lib.ABI_VERSION
+    for name in ('uniform', 'nearest', 'point_grad', 'mark_written'):
         assert callable(getattr(g, name))
     with pytest.raises(RuntimeError, match='no CPU path'):
         g.uniform(torch.zeros(8), 16, 256, False, 0.0, False, 0, False, False)

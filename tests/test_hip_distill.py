@@ -179,10 +179,17 @@ def test_graph_replay_matches_eager():
     _settle_miopen()
     a, b = make('multi'), make('multi')
     x0, y0 = synthetic_batch(16, DEV, seed=0)
-    # same history on both: capture() runs 3 warm-up steps on its static batch
-    for _ in range(3):
-        a.step(x0, y0)
+    # capture() warms up with real steps on its static batch but puts the training state back: masters, batch-norm
+    # buffers and optimizer state are what they were (on several ranks the warm-up steps would otherwise pull the replicas apart)
+    a.step(x0, y0)
+    b.step(x0, y0)                                           # (so that momentum buffers exist before the capture)
+    master0 = b.flat_master.clone()
+    buffers0 = [t.clone() for t in b.student.buffers()]
+    momentum0 = b.opt.state[b.flat_master]['momentum_buffer'].clone()
     b.capture(x0, y0, warmup=3)
+    assert torch.equal(b.flat_master, master0)
+    assert all(torch.equal(t, t0) for t, t0 in zip(b.student.buffers(), buffers0))
+    assert torch.equal(b.opt.state[b.flat_master]['momentum_buffer'], momentum0)
     assert torch.allclose(a.flat_master, b.flat_master, rtol=1e-4, atol=1e-6)
     for step in range(3):
         x, y = synthetic_batch(16, DEV, seed=10 + step)
@@ -197,12 +204,11 @@ def test_graph_replay_with_two_batch_shapes():
     _settle_miopen((16, 8))
     a, b = make('multi'), make('multi')
     big, small = synthetic_batch(16, DEV, seed=0), synthetic_batch(8, DEV, seed=1)
-    for _ in range(3):                                       # the history capture_shapes' warm-up gives b
-        a.step(*big)
-        a.step(*small)
-    b.capture_shapes([big, small, big], warmup=3)
+    master0 = b.flat_master.clone()
+    b.capture_shapes([big, small, big], warmup=3)            # captured before any step: the momentum buffers it creates start at zero
     assert len(b._graphs) == 2
-    assert torch.allclose(a.flat_master, b.flat_master, rtol=1e-4, atol=1e-6)
+    assert torch.equal(b.flat_master, master0) and torch.equal(a.flat_master, b.flat_master)
+    assert float(b.opt.state[b.flat_master]['momentum_buffer'].abs().max()) == 0.0
     for step in range(4):
         x, y = synthetic_batch(16 if step % 2 == 0 else 8, DEV, seed=20 + step)
         la, lb = a.step(x, y), b.step(x, y)
