@@ -133,7 +133,7 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         xd = [x[:64000000] for x in xs]
         add('K1 4-bit b256 N=64,000,000', 'k_bucket_vec<QDQ,16,4,1>', uq(xd, 16, 256), 8, 64000000)
         del xd
-    add('K1g uniform 4-bit bucket_size=None', 'k_minmax_partial+k_minmax_final+k_single_apply<QDQ>', uq(xs, 16, None), 12, N,
+    add('K1g uniform 4-bit bucket_size=None', 'k_minmax_partial+final+k_single_apply<QDQ>', uq(xs, 16, None), 12, N,
         note='3 launches: reduce, fold, apply')
     if sweeps:
         add('K1s uniform 4-bit b256 stochastic', 'k_bucket_vec<QDQ,16,4,1>', uq(xs, 16, 256, stochastic_rounding=True), 8, N)

@@ -23,6 +23,11 @@ Outputs (all small, committed):
                    assign_bits_automatically, huffman mean bit length
   coords.npz       cart2hyperspherical / hypershperical2cart / invert_pytorch_vector / findFirstNonZeroIndex
   big_checksums.json   float64 checksums / histograms of larger runs (no tensors stored)
+  mean_options.npz subtract_mean=True on inputs built so that a last-bit change of the mean flips levels, with the
+                   reference run at several torch thread counts (its fp32 mean depends on them)
+
+    python tests/golden/gen_golden.py [name ...]      only the named outputs (uniform, nonuniform, ste, misc,
+                                                      nonuniform_options, nonfinite, coords, big, mean_options)
 """
 import inspect
 import json
@@ -465,12 +470,56 @@ def run_big():
     print('big done')
 
 
+def run_mean_options():
+    """subtract_mean=True (ref: quant_functions.py:66-70,148) where the LAST BIT of the mean matters.
+
+    The reference computes the mean with torch's fp32 CPU sum, whose value depends on how the sum is blocked: on the thread
+    count and the SIMD width of the box (1-2 ulps here between 1, 2, 4 and 8 threads).  These cases make that visible:
+    values on a (k + 0.5) * step grid -- every element sits exactly on a rounding boundary of the level computation once
+    the mean is subtracted and added back -- plus noise-free offsets whose fp32 and float64 sums differ.  For every case the
+    reference is run at 1, 2, 4 and 8 threads; the mean and the quantized tensor of each run are stored, so that a test
+    can tell a deviation that comes from the mean scalar (explained by one of these runs or by the correctly rounded mean)
+    from an arithmetic difference."""
+    out, meta = {}, []
+    g = gen(4242)
+    cases = []
+    for i in range(20):
+        n = [4099, 40003, 65536, 70001, 100003][i % 5]
+        s = [16, 4, 16, 256][i % 4]
+        bucket = [256, None, 100, 256][(i // 2) % 4]
+        step = [1.0, 0.25, 0.1, 3.0][i % 4]
+        cases.append((n, s, bucket, step, i))
+    for n, s, bucket, step, i in cases:
+        lev = torch.randint(0, s - 1, (n,), generator=g).float()
+        # (level + 0.5) * step: the half-way points of the level grid of the range [0, (s-1)*step], which one element at each
+        # end pins in every bucket; then shifted by an offset whose fp32 sum is inexact
+        x = (lev + 0.5) * step
+        x[::47] = 0.0
+        x[1::47] = (s - 1) * step
+        offset = [0.1, 1.0 / 3.0, 1e-3, 7.7][i % 4]
+        x = (x + offset).contiguous()
+        k = 'm%03d_' % i
+        out[k + 'x'] = x.numpy()
+        runs = {}
+        stored = {}                                      # mean -> thread count whose q is stored (one q per distinct mean)
+        for th in (1, 2, 4, 8):
+            torch.set_num_threads(th)
+            q, sf = refq.uniformQuantization(x, s, bucket_size=bucket, subtract_mean=True)
+            runs[th] = float(sf.mean_tensor)
+            if runs[th] not in stored:
+                stored[runs[th]] = th
+                out[k + 'q_t%d' % th] = q.numpy()
+        torch.set_num_threads(1)
+        meta.append(dict(n=n, s=s, bucket=bucket, step=step, offset=offset, mean_by_threads={str(t): m for t, m in runs.items()},
+                         q_stored_for_threads=sorted(stored.values()), mean_f64=float(x.double().mean())))
+    out['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, 'mean_options.npz'), **out)
+    distinct = sum(1 for m in meta if len(set(m['mean_by_threads'].values())) > 1)
+    print('mean_options cases:', len(meta), '; the reference disagrees with itself across thread counts on', distinct)
+
+
 if __name__ == '__main__':
-    run_uniform()
-    run_nonuniform()
-    run_ste()
-    run_misc()
-    run_nonuniform_options()
-    run_nonfinite()
-    run_coords()
-    run_big()
+    todo = dict(uniform=run_uniform, nonuniform=run_nonuniform, ste=run_ste, misc=run_misc, nonuniform_options=run_nonuniform_options,
+                nonfinite=run_nonfinite, coords=run_coords, big=run_big, mean_options=run_mean_options)
+    for name in (sys.argv[1:] or list(todo)):
+        todo[name]()

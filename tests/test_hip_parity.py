@@ -37,6 +37,53 @@ def _need_gpu():
     oc.build()
 
 
+def level_flips(q, q_ref, alpha_ref, s, bucket):
+    """(number of elements of q that sit on another quantization level than q_ref, largest |q - q_ref| among the others).
+    Two outputs of the same element differ by a last-bit effect (the mean's rounding, carried through x - m + m) or by a
+    whole level, alpha / (s - 1): half a level separates the two."""
+    q, q_ref = np.asarray(q, np.float64).reshape(-1), np.asarray(q_ref, np.float64).reshape(-1)
+    a = np.asarray(alpha_ref, np.float64).reshape(-1)
+    n = q.size
+    per_elem = np.repeat(a, bucket)[:n] if (bucket is not None and n >= bucket and a.size > 1) else np.full(n, a[0])
+    d = np.abs(q - q_ref)
+    flipped = d > 0.5 * per_elem / (s - 1)
+    rest = d[~flipped]
+    return int(flipped.sum()), float(rest.max()) if rest.size else 0.0
+
+
+def test_subtract_mean_where_the_last_bit_of_the_mean_flips_levels():
+    """subtract_mean=True (ref: quant_functions.py:66-70,148) on inputs where every element sits on a rounding boundary of the
+    level computation (tests/golden/gen_golden.py run_mean_options).  The reference's mean is torch's fp32 CPU sum, which
+    changes with the thread count (the golden holds its runs at 1 / 2 / 4 / 8 threads: up to 4 distinct means per case, and
+    outputs that differ from EACH OTHER by whole levels on thousands of elements).  So there is no reference bit pattern to
+    hit; what is defined and checked: the device mean is the correctly rounded mean, the output is bit-identical to the
+    oracle given that mean, the oracle given any of the reference's means reproduces that reference run bit for bit
+    (tests/test_oracle_golden.py), and where the device's mean EQUALS one of the reference's, so does the output."""
+    import conftest
+    G = conftest.load_golden('mean_options.npz')
+    equal_runs = flips_seen = 0
+    for i, c in enumerate(G.meta):
+        x = G.arr('m', i, 'x')
+        q, sf = quantization.uniformQuantization(dev(x), c['s'], bucket_size=c['bucket'], subtract_mean=True)
+        m = np.float32(float(sf.mean_tensor))
+        assert m == np.float32(x.astype(np.float64).sum() / x.size), (i, c)
+        ref = onp.uniform_quantize(x, c['s'], c['bucket'], False, True, mean=float(m))
+        assert np.array_equal(host(q), ref['q']) and np.array_equal(host(sf.alpha).reshape(-1), ref['alpha'].reshape(-1)), (i, c)
+        for th in c['q_stored_for_threads']:
+            m_ref = np.float32(c['mean_by_threads'][str(th)])
+            q_ref = G.arr('m', i, 'q_t%d' % th)
+            if m_ref == m:
+                equal_runs += 1
+                assert np.array_equal(host(q), q_ref), (i, th)
+            else:
+                flips, worst = level_flips(host(q), q_ref, host(sf.alpha), c['s'], c['bucket'])
+                flips_seen += flips
+                assert worst <= 1e-6 * float(np.abs(x).max()), (i, th, worst)
+                assert abs(float(m) - float(m_ref)) <= 8 * np.spacing(np.float32(abs(m))), (i, th)     # the reference's means: 1-4 ulps around it
+    assert equal_runs >= 3                        # some reference runs do land on the correctly rounded mean
+    assert flips_seen > 0                         # ... and the others differ by whole levels: the cases are adversarial
+
+
 # ------------------------------------------------------------------------------ uniform (K1/K1g/K2/K3)
 def test_uniform_golden(golden_uniform):
     G = golden_uniform
@@ -54,10 +101,17 @@ def test_uniform_golden(golden_uniform):
         if c['subtract_mean']:
             m = float(sf.mean_tensor)
             errlog.check_mean('qd_mean_f32 vs the reference fp32 mean (golden)', m, c['mean'], float(np.abs(x).mean()), tag, n_terms=x.size)
+            # the device mean is the correctly rounded one (float64 accumulation, one rounding); the reference's fp32 sum is
+            # 0-2 ulps away from it depending on torch's thread count (tests/golden/mean_options.npz)
+            assert np.float32(m) == np.float32(x.astype(np.float64).sum() / x.size), tag
             # everything downstream of the mean is bit-exact given the mean the device computed
             ref = onp.uniform_quantize(x, c['s'], c['bucket'], c['max_element'], True, mean=m)
             assert np.array_equal(host(q), ref['q']), tag
             assert np.array_equal(host(sf.alpha).reshape(-1), ref['alpha'].reshape(-1)), tag
+            # ... and DIRECTLY against the reference's output: no element on another level, values within 1e-6 max|x|
+            flips, worst = level_flips(host(q), G.arr('u', i, 'q'), G.arr('u', i, 'alpha'), c['s'], c['bucket'])
+            assert flips == 0, (tag, 'elements on another level than the reference put them', flips)
+            assert worst <= 1e-6 * float(np.abs(x).max()), (tag, worst)
             continue
         assert np.array_equal(host(q), G.arr('u', i, 'q')), tag
         assert np.array_equal(host(sf.alpha), G.arr('u', i, 'alpha')), tag
@@ -990,6 +1044,10 @@ def test_nonuniform_options_golden(golden_nonuniform_options):
             errlog.check_mean('qd_mean_f32 vs the reference fp32 mean (golden)', m, c['mean'], float(np.abs(x).mean()), (i, c), n_terms=x.size)
             r = onp.nonuniform_quantize(x, pts, c['bucket'], 'distance', c['max_element'], True, mean=m)
             assert np.array_equal(host(idx), r['idx']) and np.array_equal(host(q), r['q']), (i, c)
+            # directly against the reference's output: the same point for every element, values within 1e-6 max|x|
+            assert np.array_equal(host(idx), G.arr('o', i, 'idx')), (i, c, int((host(idx) != G.arr('o', i, 'idx')).sum()))
+            assert np.abs(host(q).astype(np.float64) - G.arr('o', i, 'q')).max() <= 1e-6 * float(np.abs(x).max()), (i, c)
+            assert np.array_equal(host(ip), G.arr('o', i, 'idx_pre')), (i, c)
             m2 = float(fn.scaling_function.mean_tensor)
             r2 = onp.nonuniform_quantize(x, pts, c['bucket'], 'midpoint', c['max_element'], True, mean=m2)
             assert np.array_equal(host(ip), r2['idx']) and np.array_equal(host(qp), r2['q']), (i, c)

@@ -169,3 +169,26 @@ def test_nonuniform_options(golden_nonuniform_options):
             r = onp.nonuniform_quantize(x, pts, c['bucket'], mode, c['max_element'], c['subtract_mean'], mean=mean)
             assert np.array_equal(r['idx'], G.arr('o', i, ik)), (i, c, mode)
             assert np.array_equal(r['q'], G.arr('o', i, qk)), (i, c, mode)
+
+
+def test_mean_options_oracle_reproduces_every_reference_run():
+    """tests/golden/mean_options.npz: the reference at 1 / 2 / 4 / 8 torch threads on inputs whose elements sit on rounding
+    boundaries.  Given the mean of a run, the oracle reproduces that run bit for bit -- so the only thing that separates two
+    runs (or the device from a run) is the mean scalar.  Also pins what the file is for: the reference disagrees with itself."""
+    from conftest import load_golden
+    G = load_golden('mean_options.npz')
+    self_disagreements = whole_level = 0
+    for i, c in enumerate(G.meta):
+        x = G.arr('m', i, 'x')
+        runs = {}
+        for th in c['q_stored_for_threads']:
+            mean = c['mean_by_threads'][str(th)]
+            r = onp.uniform_quantize(x, c['s'], c['bucket'], False, True, mean=mean)
+            assert np.array_equal(r['q'], G.arr('m', i, 'q_t%d' % th)), (i, th)
+            runs[th] = r['q']
+        if len(runs) > 1:
+            self_disagreements += 1
+            a, *rest = runs.values()
+            step = float(np.abs(x).max()) / c['s'] / 4
+            whole_level += sum(int((np.abs(a.astype(np.float64) - b) > step).sum()) for b in rest)
+    assert self_disagreements >= 5 and whole_level > 1000

@@ -16,6 +16,8 @@
 #   side       tools/side_output_probe.py (calls with index / level side outputs at every bucket-size family; SIDE_ARGS)
 #   spread     tools/distill_spread_probe.py: repetition-to-repetition spread of the configs[1] step, with a kernel trace
 #   stack      ROCm / driver / torch versions of the box
+#   coverage   tools/launch_coverage.py --run: the GPU suite under rocprofv3 --kernel-trace --stats, shipped kernels never launched
+#   dispatch   tools/dispatch_map.py --trace: call geometry -> kernel map
 set +e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
@@ -63,6 +65,8 @@ for step in "$@"; do
              (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/spread_trace -o spread -- python $R/tools/distill_spread_probe.py --marks --reps 8 > $R/gpurun_out/distill_spread_traced.txt 2> $R/gpurun_out/spread.err); echo "trace rc=$?"
              python tools/distill_spread_probe.py --analyse gpurun_out/spread_trace > gpurun_out/distill_spread_analysis.txt 2>&1; cat gpurun_out/distill_spread_analysis.txt
              find gpurun_out/spread_trace -name '*.csv' -size +8M -delete ;;
+    coverage) timeout 3000 python tools/launch_coverage.py --run > gpurun_out/launch_coverage.log 2>&1; echo "coverage rc=$?"; head -40 gpurun_out/launch_coverage.txt; tail -5 gpurun_out/launch_coverage.log ;;
+    dispatch) timeout 1200 python tools/dispatch_map.py --trace > gpurun_out/dispatch_map.log 2>&1; echo "dispatch rc=$?"; head -30 gpurun_out/dispatch_map.txt; tail -3 gpurun_out/dispatch_map.log ;;
     *)       echo "unknown step $step" ;;
   esac
 done
