@@ -748,7 +748,7 @@ def main():
     if isinstance(roofline.get('kernels'), list):
         from harness.kernel_bench import flat_row
         for i, r in enumerate(roofline['kernels']):
-            roofline['k%02d' % (i + 1)] = flat_row(r)[:118]
+            roofline['k%02d' % (i + 1)] = flat_row(r)
 
     # RCCL writes a version banner to the C-level stdout, which is block-buffered when piped and would
     # otherwise be flushed at exit, i.e. after the JSON line: push it out now on every rank, so that the JSON

@@ -1,5 +1,8 @@
 """Achieved algorithmic bandwidth of every kernel on the path, measured the same way everywhere.
 
+(The `kernel` column names what rocprofv3 shows for the call -- tools/dispatch_map.py, profiles/r04_dispatch_map.txt; template
+arguments: mode 0 = quantize-dequantize, 1 = scale_down, 2 = nearest point.)
+
 One table of rows (the headline's secondary rows and the per-kernel byte bases of
 K2 ... K9), one timing routine, two users: bench.py's `kernels` leg (so that every row is in the
 driver's record, not only in builder-run profiles) and tools/bench_kernels.py (which adds the
@@ -90,9 +93,11 @@ def format_row(r):
         r['name'], r['kernel'], r['us'], r['us_min'], r['us_max'], r['bytes_per_elem'], r['GBps'], 100 * r['frac'], r.get('note', ''))
 
 
-def flat_row(r):
-    """One row as a short string (the driver's record keeps scalars of the roofline object, not nested lists)."""
-    return '%s | %s | %.2f us | %g B/el | %.0f GB/s | %.3f' % (r['name'], r['kernel'], r['us'], r['bytes_per_elem'], r['GBps'], r['frac'])
+def flat_row(r, width=118):
+    """One row as a short string (the driver's record keeps scalars of the roofline object, not nested lists, and cuts strings):
+    the numbers first, the kernel name last and shortened if need be."""
+    s = '%s | %.2f us | %g B/el | %.0f GB/s | %.3f | ' % (r['name'], r['us'], r['bytes_per_elem'], r['GBps'], r['frac'])
+    return (s + r['kernel'])[:width]
 
 
 def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist_log2n=30):
@@ -121,44 +126,45 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         return lambda i: keep(i, quantization.uniformQuantization(src[i % R], s, bucket_size=b, **kw)[0])
 
     # ---- K1: the headline call and SURVEY 8d's secondary rows
-    add('K1 uniform 4-bit b256 (headline)', 'k_bucket_vec<QDQ,16,4,1>', uq(xs, 16, 256), 8, N)
-    add('K1 uniform 2-bit (s=4) b256', 'k_bucket_vec<QDQ,16,4,1>', uq(xs, 4, 256), 8, N)
+    add('K1 uniform 4-bit b256 (headline)', 'k_bucket_vec<0,16,4,1>', uq(xs, 16, 256), 8, N)
+    add('K1 uniform 2-bit (s=4) b256', 'k_bucket_vec<0,16,4,1>', uq(xs, 4, 256), 8, N)
     xw = [x * 0.05 for x in xs]
-    add('K1 4-bit b256 weight-like 0.05*randn', 'k_bucket_vec<QDQ,16,4,1>', uq(xw, 16, 256), 8, N)
+    add('K1 4-bit b256 weight-like 0.05*randn', 'k_bucket_vec<0,16,4,1>', uq(xw, 16, 256), 8, N)
     del xw
     xr = [randn(N + 17) for _ in range(R)]
-    add('K1 4-bit b256 ragged N=64Mi+17', 'k_bucket_vec<QDQ,16,4,1>', uq(xr, 16, 256), 8, N + 17)
+    add('K1 4-bit b256 ragged N=64Mi+17', 'k_bucket_vec<0,16,4,1>', uq(xr, 16, 256), 8, N + 17)
     del xr
     if log2n == 26:
         xd = [x[:64000000] for x in xs]
-        add('K1 4-bit b256 N=64,000,000', 'k_bucket_vec<QDQ,16,4,1>', uq(xd, 16, 256), 8, 64000000)
+        add('K1 4-bit b256 N=64,000,000', 'k_bucket_vec<0,16,4,1>', uq(xd, 16, 256), 8, 64000000)
         del xd
-    add('K1g uniform 4-bit bucket_size=None', 'k_minmax_partial+final+k_single_apply<QDQ>', uq(xs, 16, None), 12, N,
+    add('K1g uniform 4-bit bucket_size=None', 'k_minmax_partial+k_minmax_final+k_single_apply<0>', uq(xs, 16, None), 12, N,
         note='3 launches: reduce, fold, apply')
     if sweeps:
-        add('K1s uniform 4-bit b256 stochastic', 'k_bucket_vec<QDQ,16,4,1>', uq(xs, 16, 256, stochastic_rounding=True), 8, N)
+        add('K1s uniform 4-bit b256 stochastic', 'k_bucket_vec<0,16,4,1>', uq(xs, 16, 256, stochastic_rounding=True), 8, N)
         for b in (64, 128, 512, 1024, 2048, 4096, 8192, 100, 36, 33, 50, 250, 513, 1000, 1001, 2000, 3000, 5000, 8000):
             add('K1 uniform 4-bit bucket %d' % b, '(dispatch map)', uq(xs, 16, b), 8, N, iters=ITERS if b in (64, 128, 512, 1024, 2048) else 12)
 
     # ---- K2 / K3
     sf = quantization.ScalingFunction('linear', False, False, 256)
-    add('K2 scale_down b256', 'k_bucket_vec<SCALE,16,4,1>', lambda i: keep(i, sf.scale_down(xs[i % R])), 8, N)
+    add('K2 scale_down b256', 'k_bucket_vec<1,16,4,1>', lambda i: keep(i, sf.scale_down(xs[i % R])), 8, N)
     us_ = [sf.scale_down(x) for x in xs[:3]]
-    add('K3 inv_scale_down b256', 'k_inv_scale', lambda i: keep(i, sf.inv_scale_down(us_[i % 3])), 8, N)
+    add('K3 inv_scale_down b256', 'k_inv_scale<false>', lambda i: keep(i, sf.inv_scale_down(us_[i % 3])), 8, N)
     del us_
 
     # ---- K4 / K5 / K6
     gs = [randn(N) for _ in range(R)]
     for k in ((4, 16, 256) if sweeps else (4, 16)):
         pts = torch.sort(torch.rand(k, device=dev, generator=gen))[0]
-        add('K4 nonUniform k=%d b256 (int64 idx)' % k, 'k_bucket_vec<NEAREST,16,4,1>',
+        add('K4 nonUniform k=%d b256 (int64 idx)' % k, 'k_bucket_vec<2,16,4,1>',
             lambda i, pts=pts: keep(i, quantization.nonUniformQuantization(xs[i % R], pts, bucket_size=256)[0]), 16, N)
         fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=xs[j]) for j in range(3)]
-        add('K5 diff-quant forward k=%d (u resident, u8 idx)' % k, 'k_nearest_stream',
+        add('K5 diff-quant forward k=%d (u resident, u8 idx)' % k, 'k_nearest_prescaled_stream<false>',
             lambda i, pts=pts, fns=fns: fns[i % 3].forward(None, pts), 9, N)
         for f in fns:
             f.forward(None, pts)
-        add('K6 point gradient k=%d (u8 idx)' % k, 'k_point_grad', lambda i, fns=fns: fns[i % 3].backward(gs[i % R]), 5, N)
+        add('K6 point gradient k=%d (u8 idx)' % k, 'k_point_grad_fast<%d,1,1,4,..>+k_point_grad_final' % (4 if k <= 4 else 0),
+            lambda i, fns=fns: fns[i % 3].backward(gs[i % R]), 5, N)
         del fns
 
     # ---- K7 / K8
@@ -168,7 +174,7 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         f = fq[i % R]
         f.saved_for_backward = {'input': xs[i % R]}
         keep(i, f.backward(gs[(i + 1) % R]))
-    add("K7 'complicated' STE backward b256", 'k_ste_bucket', k7, 12, N)
+    add("K7 'complicated' STE backward b256", 'k_ste_backward_vec<16,4>', k7, 12, N)
     st_ptr = _lib.stream_ptr
     add('K8 truncated STE mask, 32% of |w| > 1', 'k_truncated_ste',
         lambda i: lib.qd_truncated_ste_f32(xs[i % R].data_ptr(), gs[i % R].data_ptr(), N, 1.0, st_ptr()), 12, N,
@@ -184,16 +190,16 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
     pks = [None] * R
     add('PK pack 4-bit levels + alpha/beta b256', 'k_pack_vec<16,4,4>', lambda i: pks.__setitem__(i % R, codec.pack_uniform(xs[i % R], 16, 256)), 4.5, N)
     pk = [codec.pack_uniform(xs[j], 16, 256) for j in range(R)]
-    add('UPK unpack 4-bit -> fp32 b256', 'k_unpack<4>', lambda i: keep(i, pk[i % R].unpack()), 4.5, N)
+    add('UPK unpack 4-bit -> fp32 b256', 'k_unpack_wide<4>', lambda i: keep(i, pk[i % R].unpack()), 4.5, N)
     del pks, pk
-    add('LVH level histogram of x, s=16 b256', 'k_bucket_vec<QDQ..lev8>+k_hist', lambda i: codec.level_histogram(xs[i % R], 16, 256), 5, N,
+    add('LVH level histogram of x, s=16 b256', 'k_pack_vec<16,4,8>+k_hist_atomic<2>+k_hist_fold', lambda i: codec.level_histogram(xs[i % R], 16, 256), 5, N,
         note='levels only (no q): 4 B read + 1 B written, + 1 B read by the count')
     live[:] = [None] * R
     del xs
     NH = 1 << hist_log2n
     lev8 = [torch.randint(0, 16, (NH,), dtype=torch.uint8, device=dev, generator=gen) for _ in range(3)]
     for k in (16, 256):
-        add('HST histogram of u8 levels k=%d, %d Mi symbols' % (k, NH >> 20), 'k_hist_atomic', lambda i, k=k: codec.histogram_u8(lev8[i % 3], k), 1, NH,
+        add('HST histogram of u8 levels k=%d, %d Mi symbols' % (k, NH >> 20), 'k_hist_atomic<2>+k_hist_fold', lambda i, k=k: codec.histogram_u8(lev8[i % 3], k), 1, NH,
             iters=12)
     del lev8
 
@@ -205,7 +211,7 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         for _ in range(nset):
             masters = [randn(torch.Size(s).numel()).view(s) for s in shapes]
             sets.append((masters, MultiTensorQuantizer(masters, 16, 256)))
-        add('K9 multi-tensor uniform 4-bit, %s' % tag, 'k_multi_uniform', lambda i: sets[i % nset][1].quantize(check_pointers=False), 8, tot, iters=iters)
+        add('K9 multi-tensor uniform 4-bit, %s' % tag, 'k_multi_uniform<256>', lambda i: sets[i % nset][1].quantize(check_pointers=False), 8, tot, iters=iters)
         if sweeps:
             add('   same tensors, per-tensor API loop', '(per tensor)', lambda i: [quantization.uniformQuantization(m, 16, bucket_size=256) for m in sets[i % nset][0]],
                 8, tot, iters=10)
@@ -218,8 +224,8 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         gr = [torch.randn_like(m) for m in masters]
         mdq.append(MultiTensorDiffQuant(masters, qs, gr, 4, 256))
     ptsm = torch.sort(torch.rand(len(sets[0][0]), 4, device=dev, generator=gen), dim=1)[0].contiguous()
-    add('K5m multi-tensor assign k=4, WRN-16-22', 'k_multi_nearest', lambda i: mdq[i % nset].forward(ptsm), 9, tot)
-    add('K6m multi-tensor point gradient k=4, WRN-16-22', 'k_multi_point_grad', lambda i: mdq[i % nset].backward(), 5, tot)
+    add('K5m multi-tensor assign k=4, WRN-16-22', 'k_multi_nearest<256>', lambda i: mdq[i % nset].forward(ptsm), 9, tot)
+    add('K6m multi-tensor point gradient k=4, WRN-16-22', 'k_multi_point_grad+k_multi_point_grad_final', lambda i: mdq[i % nset].backward(), 5, tot)
     del mdq, sets
     multi_rows('CIFAR student 22 tensors 1.0 M', model_shapes('student'), 200)
     return out.rows

@@ -1876,17 +1876,8 @@ int launch_bucketed(KParams& p, hipStream_t st) {
             return check_launch();
         }
     }
-    if (aligned && p.nb > 1 && (p.row & 3) != 0 && p.row > 512 && p.row <= 1024) {     // four buckets per chunk, 16 float4 per lane
-        const int64_t nchunks = nfull / 4;
-        if (nchunks > 0) {
-            const size_t lds = (size_t)2 * (16 * 256 + (stage8 ? 16 * 64 : 0)) * sizeof(float);
-            const int blocks = blocks_for(nchunks, 2) + 1;
-            p.fine = 0;
-            hipLaunchKernelGGL((k_bucket_chunk_any<MODE, 16>), dim3(blocks), dim3(128), lds + tbc, st, p, 4, nchunks,
-                               p.row * 4 + 28 <= 16 * 256 ? 1 : 0);
-            return check_launch();
-        }
-    }
+    // (bucket sizes 513 .. 1023 that are not a multiple of 4 once had a 16-float4 instance of k_bucket_chunk_any here; since
+    // k_bucket_wave_any takes every size above 512 the branch was unreachable -- tools/launch_coverage.py -- and is gone)
     if (p.row <= 256) {                                  // 16 buckets per block, a DPP row each
         hipLaunchKernelGGL((k_bucket_groups<MODE, 16>), dim3(blocks_for(p.nb, 16) < fine_cap ? blocks_for(p.nb, 16) : fine_cap), dim3(256), tb, st, p);
     } else if (p.row <= 16384) {                         // 4 buckets per block, one wave each

@@ -139,3 +139,25 @@ def test_point_gradient_vs_the_staged_reference_on_wrn_shapes():
         errlog.check_sum('K6 vs float64 oracle, WRN-16-22 shapes', gp.cpu().numpy(), wg, absum, tag, n_terms=t.numel())
         errlog.check_sum("the staged reference's fp32 gradPointTensor vs float64 oracle, WRN-16-22 shapes", gpr.cpu().numpy(), wg, absum, tag,
                          n_terms=t.numel(), tol=1e-5)
+
+
+@pytest.mark.parametrize('bucket', [64, 128, 512])
+def test_multi_tensor_diffquant_at_the_other_power_of_two_bucket_sizes(bucket):
+    """qd_multi_nearest_f32 / qd_multi_point_grad_f32 have an instance per bucket size 64 / 128 / 256 and one for any other
+    power of two: the CIFAR student's shape list at those sizes, k = 4 and 16, against the C oracle."""
+    host = _weights('cifar_student')
+    dev = [t.to(DEV) for t in host]
+    g_host = [torch.randn(t.shape, generator=torch.Generator().manual_seed(70 + i)) * 1e-2 for i, t in enumerate(host)]
+    grads = [g.to(DEV) for g in g_host]
+    for k in (4, 16):
+        pts = torch.sort(torch.rand(len(host), k, generator=torch.Generator().manual_seed(k)), dim=1)[0].contiguous()
+        outs = [torch.empty_like(t) for t in dev]
+        mt = MultiTensorDiffQuant(dev, outs, grads, k, bucket)
+        mt.forward(pts.to(DEV))
+        gp = mt.backward().cpu().numpy().astype(np.float64)
+        for i, t in enumerate(host):
+            want = oracle_c.nonuniform_quantize(t.numpy(), pts[i].numpy(), bucket, mode='midpoint')
+            assert np.array_equal(outs[i].cpu().numpy(), want['q']), (bucket, k, i)
+            assert np.array_equal(mt.indices[i].cpu().numpy(), want['idx'].reshape(-1).astype(np.uint8)), (bucket, k, i)
+            wg, absum = oracle_c.point_grad(g_host[i].numpy(), want['idx'], want['alpha'], bucket, k)
+            errlog.check_sum('K6m multi-tensor point gradient, bucket %d' % bucket, gp[i], wg, absum, (k, i), n_terms=t.numel())

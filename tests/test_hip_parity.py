@@ -252,8 +252,8 @@ def test_uniform_chunk_kernels_many_chunks_per_wave(bucket):
     assert np.array_equal(host(qs), want['q'])
 
 
-@pytest.mark.parametrize('bucket', [257, 300, 511, 513, 600, 770, 1000, 1001, 1023, 1500, 2000, 2049, 3000, 4093, 5000, 6145,
-                                    8000, 8190, 8200, 10001, 16384, 20000, 32768, 32769])
+@pytest.mark.parametrize('bucket', [257, 300, 449, 511, 513, 600, 770, 1000, 1001, 1023, 1500, 1700, 2000, 2049, 3000, 3500, 4093, 5000,
+                                    6000, 6145, 8000, 8190, 8200, 10001, 16384, 20000, 32768, 32769])
 def test_uniform_wave_per_bucket_any_size(bucket):
     """Bucket sizes above 256 that are not one of the vector sizes: one wave per bucket on the aligned float4s that touch
     it (k_bucket_wave_any).  Tensor ends at, just after and well after a bucket boundary (the last buckets go to the tail
@@ -291,7 +291,28 @@ def test_uniform_wave_per_bucket_any_size(bucket):
     assert np.array_equal(host(h), np.bincount(oc.uniform_quantize(x, 16, bucket)['lev'], minlength=16))
 
 
-@pytest.mark.parametrize('bucket', [33, 255, 300, 506, 509, 511, 513, 1000, 1001, 1017, 1023, 2000, 3001, 5000, 8190, 12000, 30000])
+def test_few_buckets_of_a_large_bucket_size():
+    """Tensors with too few buckets to fill one chunk of the chunk kernels fall through to the lane-group kernels
+    (k_bucket_groups<MODE, 64>: a wave per bucket, two passes): every mode, bit-exact against the C oracle."""
+    rng = np.random.RandomState(77)
+    pts = np.array([0.0, 0.25, 0.7, 1.0], np.float32)
+    for n, bucket in ((700, 300), (900, 400), (1300, 260), (1001, 500)):
+        x = rng.randn(n).astype(np.float32)
+        xd = dev(x)
+        for s_ in (16, 4):
+            q, sf = quantization.uniformQuantization(xd, s_, bucket_size=bucket)
+            r = oc.uniform_quantize(x, s_, bucket)
+            assert np.array_equal(host(q), r['q']) and np.array_equal(host(sf.alpha).reshape(-1), r['alpha']), (n, bucket, s_)
+        sfn = quantization.ScalingFunction('linear', False, False, bucket)
+        u = sfn.scale_down(xd)
+        assert np.array_equal(host(u).reshape(-1)[:n], oc.scale_down(x, bucket)['u']), (n, bucket)
+        qn, idx, _ = quantization.nonUniformQuantization(xd, dev(pts), bucket_size=bucket)
+        rn = oc.nonuniform_quantize(x, pts, bucket)
+        assert np.array_equal(host(qn), rn['q']) and np.array_equal(host(idx), rn['idx']), (n, bucket)
+
+
+@pytest.mark.parametrize('bucket', [33, 255, 300, 506, 509, 511, 513, 1000, 1001, 1017, 1023, 2000, 2048, 3001, 4000, 4096, 5000, 8190, 12000,
+                                    30000])
 def test_other_modes_at_chunk_sizes(bucket):
     """scale_down and nonUniformQuantization at bucket sizes of the chunk kernels (with and without the lead-in to the
     128-byte line): bit-exact against the C oracle."""
@@ -546,7 +567,7 @@ def test_nonuniform_random_vs_c_oracle(k):
 
 @pytest.mark.parametrize('bucket,k', [(100, 4), (100, 600), (1000, 4), (1000, 600), (100, 64), (100, 100), (33, 16), (256, 600),
                                       (None, 700), (256, 1024), (1000, 1024), (100, 128), (1000, 256), (7, 16), (5, 4), (6, 200),
-                                      (3, 16), (2, 4)])
+                                      (3, 16), (2, 4), (256, 100), (None, 100), (256, 300), (None, 300)])
 def test_point_gradient_deterministic_and_within_1e6_on_every_path(bucket, k):
     """qd_point_grad_f32 promises a deterministic two-stage reduction on EVERY path (include/qd_hip.h).  Round 2's path for
     non-power-of-two buckets, k > 512 and misaligned index pointers used float LDS atomics, whose order is not fixed; it
@@ -898,7 +919,8 @@ def test_beyond_int32_elements_at_a_bucket_size_that_is_not_a_power_of_two():
 def test_pack_unpack_roundtrip(s, bits):
     from quantized_distillation_amd import codec
     rng = np.random.RandomState(s)
-    for n, bucket in [(256 * 40, 256), (100003, 256), (70001, 64), (5 * 2048 + 7, 2048), (300, 256), (1 << 22, 512),
+    for n, bucket in [(256 * 40, 256), (100003, 256), (70001, 64), (5 * 2048 + 7, 2048), (300, 256), (1 << 22, 512), (128 * 33 + 5, 128),
+                      (1024 * 9 + 3, 1024),
                       (100003, 100), (100003, 33), (70001, 1000), (1 << 20, 513), (100003, None), (777, None), (5000, 3),
                       (100003, 4096), (50, 256)]:      # any bucket size: quantize with level indices + pack them
         x = rng.randn(n).astype(np.float32)
@@ -921,6 +943,35 @@ def test_pack_unpack_roundtrip(s, bits):
         assert torch.equal(y, q) and np.array_equal(host(y), ref['q'])
         # size = what helpers/functions.py:255-259 charges: bits*N/8 + 8 bytes per bucket
         assert pk.nbytes == (n * bits + 7) // 8 + 8 * (1 if (bucket is None or n < bucket) else -(-n // bucket))
+
+
+def test_unpack_wide_and_narrow_forms_agree():
+    """qd_unpack_uniform_f32 decodes whole 1 KiB chunks of the packed stream with 16-byte loads (k_unpack_wide) and the rest --
+    or everything, when the packed stream or the output is not 16-byte aligned -- four elements per lane (k_unpack): same bits."""
+    from quantized_distillation_amd import codec
+    lib = _lib.load()
+    rng = np.random.RandomState(11)
+    for s, bits in ((16, 4), (4, 2), (2, 1), (200, 8)):
+        chunk = 64 * 128 // bits
+        for n in (chunk, chunk * 5, chunk * 5 + 4, chunk * 7 + 1001, chunk - 4):
+            for bucket in (16, 256, 2048):                         # (16: packed through the level-index path, decoded by these kernels)
+                x = rng.randn(n).astype(np.float32)
+                pk = codec.pack_uniform(dev(x), s, bucket, bits=bits)
+                want = host(pk.unpack())
+                assert np.array_equal(want, oc.uniform_quantize(x, s, bucket)['q']), (s, bits, n, bucket)
+                # output 4 bytes into a 16-byte granule: the narrow form does everything
+                ybuf = torch.empty(n + 8, device=DEV)
+                y = ybuf[1:n + 1]
+                _lib.check(lib.qd_unpack_uniform_f32(pk.packed.data_ptr(), n, bucket, s, bits, pk.alpha.data_ptr(), pk.beta.data_ptr(),
+                                                     y.data_ptr(), _lib.stream_ptr()))
+                assert np.array_equal(host(y), want), (s, bits, n, bucket)
+                # packed stream 4 bytes into a granule
+                pbuf = torch.empty(pk.packed.numel() + 16, dtype=torch.uint8, device=DEV)
+                pbuf[4:4 + pk.packed.numel()].copy_(pk.packed)
+                y2 = torch.empty(n, device=DEV)
+                _lib.check(lib.qd_unpack_uniform_f32(pbuf.data_ptr() + 4, n, bucket, s, bits, pk.alpha.data_ptr(), pk.beta.data_ptr(),
+                                                     y2.data_ptr(), _lib.stream_ptr()))
+                assert np.array_equal(host(y2), want), (s, bits, n, bucket)
 
 
 def test_level_histogram_and_device_huffman(golden_misc):

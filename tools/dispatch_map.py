@@ -40,9 +40,10 @@ def calls():
     labels = []
 
     def case(label, fn):
-        torch.bitwise_xor(ma, mb)
+        torch.bitwise_xor(ma, mb)            # a marker before and after: what a case's SETUP launches is not attributed to it
         labels.append(label)
         fn()
+        torch.bitwise_xor(ma, mb)
     N = 1 << 22
     base = torch.randn(N + 64, device=dev)
     g = torch.randn(N, device=dev)
@@ -129,7 +130,6 @@ def calls():
         ptsm = torch.sort(torch.rand(len(masters), k, device=dev), dim=1)[0].contiguous()
         case('MultiTensorDiffQuant.forward k=%d bucket=256' % k, lambda: mdq.forward(ptsm))
         case('MultiTensorDiffQuant.backward k=%d bucket=256' % k, lambda: mdq.backward())
-    torch.bitwise_xor(ma, mb)
     torch.cuda.synchronize()
     with open(os.environ['QD_DISPATCH_LABELS'], 'w') as f:
         json.dump(labels, f)
@@ -155,15 +155,15 @@ def trace():
                 for row in csv.DictReader(fh):
                     rows.append((int(row['Start_Timestamp']), row['Kernel_Name']))
     rows.sort()
-    groups, cur, started = [], None, False
+    spans, cur = [], None                    # kernels between consecutive markers: inside a case, between two cases, inside, ...
     for _t, name in rows:
         if MARK in name:
             if cur is not None:
-                groups.append(cur)
-            cur, started = [], True
-        elif started:
+                spans.append(cur)
+            cur = []
+        elif cur is not None:
             cur.append(short_name(name))
-    # the last marker closes the last case; torch helper kernels (fills, sorts, copies of the case's own setup) are listed too
+    groups = spans[0::2]                     # every case is bracketed by two markers
     if len(groups) != len(labels):
         print('marker count %d != cases %d' % (len(groups), len(labels)))
     lines = ['# call -> kernels dispatched (in order; xN = N consecutive dispatches), traced with rocprofv3 --kernel-trace', '']
