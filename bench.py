@@ -575,7 +575,7 @@ def main():
 
     # Preconditioning (setup, untimed): from an idle GPU the first ~25 ms of back-to-back
     # launches run 10-30 % slower while the power/clock management settles
-    # (tools/sustain_probe.py, profiles/r01_sustain_probe.txt); bring the chip to its steady
+    # (tools/sustain_probe.py, docs/history/profiles/r01_sustain_probe.txt); bring the chip to its steady
     # state before the official warm-up so that short --warmup/--steps runs measure steady state.
     t_pre = time.time()
     n_pre = 0
@@ -652,7 +652,7 @@ def main():
         'extended_avg_launch_us': round(ext_us, 3),
         'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
         'timing': 'HIP events on the launch stream around the %d timed launches (includes inter-launch gaps)' % args.steps,
-        'torch_d2d_copy_GBps': round(copy_gbps, 1),      # torch's own copy of the same bytes, same box (a hand-written NT copy reaches 6.3-6.5 TB/s: profiles/r01_kbench.txt)
+        'torch_d2d_copy_GBps': round(copy_gbps, 1),      # torch's own copy of the same bytes, same box (a hand-written NT copy reaches 6.3-6.5 TB/s: docs/history/profiles/r01_kbench.txt)
     }
     line.update({
         'value': round(bytes_per_launch * args.steps * n_gpus / elapsed / 1e9, 2),

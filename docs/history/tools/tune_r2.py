@@ -4,7 +4,7 @@ sizes), N = 64 Mi, steady state.  Environment switches of the library (read once
 QD_PG_U=8|16|32 (K6 loads in flight per lane for tables above 64 KiB), QD_WAVE_ANY=0|1|2, QD_WAVE_ALIGN=4|16|32, QD_NO_VEC=1
 (the one-wave-per-bucket kernel: off / default sizes / every size above 256; window alignment in elements; vector sizes through it).
 TUNE_BUCKETS / TUNE_HIST_K select the rows.  (The histogram switches of the earlier sessions -- QD_HIST_REG, QD_HIST_BPC -- went with
-the kernels they selected; tools/gpu_r2c.sh / gpu_r2d.sh are kept as the record of how profiles/r02_tune_kernels.txt's first half was made.)"""
+the kernels they selected; tools/gpu_r2c.sh / gpu_r2d.sh are kept as the record of how docs/history/profiles/r02_tune_kernels.txt's first half was made.)"""
 import os
 import sys
 import time

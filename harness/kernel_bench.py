@@ -190,7 +190,7 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
     pks = [None] * R
     add('PK pack 4-bit levels + alpha/beta b256', 'k_pack_vec<16,4,4>', lambda i: pks.__setitem__(i % R, codec.pack_uniform(xs[i % R], 16, 256)), 4.5, N)
     pk = [codec.pack_uniform(xs[j], 16, 256) for j in range(R)]
-    add('UPK unpack 4-bit -> fp32 b256', 'k_unpack_wide<4>', lambda i: keep(i, pk[i % R].unpack()), 4.5, N)
+    add('UPK unpack 4-bit -> fp32 b256', 'k_unpack<4>', lambda i: keep(i, pk[i % R].unpack()), 4.5, N)
     del pks, pk
     add('LVH level histogram of x, s=16 b256', 'k_pack_vec<16,4,8>+k_hist_atomic<2>+k_hist_fold', lambda i: codec.level_histogram(xs[i % R], 16, 256), 5, N,
         note='levels only (no q): 4 B read + 1 B written, + 1 B read by the count')

@@ -115,13 +115,13 @@ __global__ __launch_bounds__(64) void k_pack_tail(const float* x, uint8_t* packe
 // writes 1 KiB per store instruction); the packed read is 4*BITS bits per lane
 template <int BITS>
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, float* y, const float* alpha, const float* beta,
-                                                int64_t n, int row_shift, float sm1, int64_t first_group) {
+                                                int64_t n, int row_shift, float sm1) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     const int64_t ngroups = (n + 3) >> 2;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
     const bool y_vec = (((uintptr_t)y) & 15) == 0;
-    for (int64_t gI = first_group + tid; gI < ngroups; gI += nth) {
+    for (int64_t gI = tid; gI < ngroups; gI += nth) {
         const int64_t e0 = gI << 2;
         const int64_t bkt = e0 >> row_shift;
         const float a = alpha[bkt], b = beta[bkt];
@@ -156,54 +156,11 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, float* y,
     }
 }
 
-// The same decode with WIDE loads of the packed stream.  k_unpack reads 4 * BITS bits per lane and store -- 2 bytes at 4 bits: a
-// wave's load instruction fetches 128 B, eight of them per 1 KiB of packed data.  Here a wave loads 1 KiB of the packed
-// stream with ONE 16-byte load per lane (the access pattern every other stream of this library uses, and the one the
-// FETCH_SIZE counter is calibrated for), parks it in LDS, and every lane picks the 4 * BITS bits of each of its 32 / BITS
-// float4 stores from there: element e of the chunk sits at bit e * BITS, the store of round r covers elements
-// 256 r + 4 lane .. + 3.  Whole chunks only (64 * 128 / BITS elements per wave); k_unpack finishes the rest.
-template <int BITS>
-__global__ __launch_bounds__(256) void k_unpack_wide(const uint8_t* packed, float* y, const float* alpha, const float* beta,
-                                                     int64_t nchunks, int row_shift, float sm1) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[4][1024];
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    constexpr int EPL = 128 / BITS;                   // elements per lane and chunk
-    constexpr int ROUNDS = EPL / 4;
-    constexpr uint32_t MASK = (1u << BITS) - 1u;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wave = uniform_wave_index(), nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t c = wave; c < nchunks; c += nwaves) {
-        const u4 bits16 = __builtin_nontemporal_load((const u4*)(packed + (c << 10)) + lane);
-        __builtin_amdgcn_wave_barrier();              // (the previous chunk's reads stay in front of this write)
-        *(u4*)(stage[w] + 16 * lane) = bits16;        // one wave writes and reads its own 1 KiB: the LDS queue of a wave is in order,
-        __builtin_amdgcn_wave_barrier();              // the compiler only has to keep the instructions in this order (no s_barrier)
-        const int64_t e_chunk = c * (64 * EPL);
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int e_in = 256 * r + 4 * lane;      // first of this lane's four elements, inside the chunk
-            uint32_t bits;
-            if (BITS == 8) bits = *(const uint32_t*)(stage[w] + e_in);
-            else if (BITS == 4) bits = *(const uint16_t*)(stage[w] + (e_in >> 1));
-            else if (BITS == 2) bits = stage[w][e_in >> 2];
-            else bits = (uint32_t)stage[w][e_in >> 3] >> (e_in & 4);
-            const int64_t e0 = e_chunk + e_in;
-            const int64_t bkt = e0 >> row_shift;
-            const float a = alpha[bkt], b = beta[bkt];
-            float out[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float lv = (float)((bits >> (k * BITS)) & MASK);
-                float t = lv / sm1;                    // same three ops as the tail of qdq()
-                float v = t * a;
-                v = v + b;
-                out[k] = v + 0.0f;
-            }
-            const f4 o = {out[0], out[1], out[2], out[3]};
-            __builtin_nontemporal_store(o, (f4*)(y + e0));
-        }
-    }
-}
-
+// (Round 4 measured a variant that loads the packed stream 16 bytes per lane -- a wave parks 1 KiB of it in LDS and decodes
+// 8 float4 stores from there: HBM traffic 1.009 x the algorithmic bytes against 1.064 x for this kernel by the PMC counters,
+// but 56-60 us against 47.9 us at 64 Mi elements, with or without a resident grid, the next chunk's load in flight, or a level
+// table in LDS.  Here the whole grid sweeps the output front to back, 1 KiB per wave and store; there every wave streams
+// into its own 8 KiB region, thousands of concurrent write streams.  profiles/r04_ab_codec.txt.)
 // uint8 level indices -> packed bits (any bucket geometry: the levels come from qd_uniform_f32's level_idx output).
 // Every thread produces one 32-bit word = 32 / BITS levels; the last, partial word byte by byte.
 template <int BITS>
@@ -567,25 +524,11 @@ int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int 
     while (((int64_t)1 << row_shift) < bucket) ++row_shift;
     hipStream_t st = (hipStream_t)stream;
     const float sm1 = (float)(levels - 1);
-    // whole 1 KiB chunks of the packed stream with wide loads (16-byte aligned streams), the rest four elements per lane
-    const int64_t chunk_elems = (int64_t)64 * (128 / bits);
-    const int64_t nchunks = ((((uintptr_t)packed) | ((uintptr_t)y)) & 15) == 0 ? n / chunk_elems : 0;
-    if (nchunks > 0) {
-        const int wb = blocks_for(nchunks, 4, 1 << 20);
-        if (bits == 8) hipLaunchKernelGGL(k_unpack_wide<8>, dim3(wb), dim3(256), 0, st, packed, y, alpha, beta, nchunks, row_shift, sm1);
-        else if (bits == 4) hipLaunchKernelGGL(k_unpack_wide<4>, dim3(wb), dim3(256), 0, st, packed, y, alpha, beta, nchunks, row_shift, sm1);
-        else if (bits == 2) hipLaunchKernelGGL(k_unpack_wide<2>, dim3(wb), dim3(256), 0, st, packed, y, alpha, beta, nchunks, row_shift, sm1);
-        else hipLaunchKernelGGL(k_unpack_wide<1>, dim3(wb), dim3(256), 0, st, packed, y, alpha, beta, nchunks, row_shift, sm1);
-    }
-    const int64_t first_group = nchunks * chunk_elems / 4;
-    const int64_t rest_groups = (n + 3) / 4 - first_group;
-    if (rest_groups > 0) {
-        const int blocks = blocks_for(rest_groups, 256 * 4, 1 << 20);
-        if (bits == 8) hipLaunchKernelGGL(k_unpack<8>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1, first_group);
-        else if (bits == 4) hipLaunchKernelGGL(k_unpack<4>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1, first_group);
-        else if (bits == 2) hipLaunchKernelGGL(k_unpack<2>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1, first_group);
-        else hipLaunchKernelGGL(k_unpack<1>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1, first_group);
-    }
+    const int blocks = blocks_for((n + 3) / 4, 256 * 4, 1 << 20);
+    if (bits == 8) hipLaunchKernelGGL(k_unpack<8>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1);
+    else if (bits == 4) hipLaunchKernelGGL(k_unpack<4>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1);
+    else if (bits == 2) hipLaunchKernelGGL(k_unpack<2>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1);
+    else hipLaunchKernelGGL(k_unpack<1>, dim3(blocks), dim3(256), 0, st, packed, y, alpha, beta, n, row_shift, sm1);
     return (int)hipGetLastError();
 }
 
@@ -595,7 +538,7 @@ int qd_histogram_u8_ws(const uint8_t* idx, int64_t n, int k, uint64_t* hist, voi
     hipStream_t st = (hipStream_t)stream;
     const int cus = device_cus();
     const size_t lds = (size_t)(k + 1) * 32 * sizeof(uint32_t);
-    // Measured at 64 Mi symbols (tools/tune_r2.py, profiles/r02_tune_kernels.txt).  Private-column tables with the four
+    // Measured at 64 Mi symbols (tools/tune_r2.py, docs/history/profiles/r02_tune_kernels.txt).  Private-column tables with the four
     // symbols of a word merged in registers (round 1 / early round 2): 35 us (k <= 64), 49 us (k = 256); register counters
     // for k <= 16: 21.5-23.5 us, unchanged by software-pipelining the loads.  This kernel with global atomics at the end of
     // each block, 1 / 2 / 4 blocks per CU: k = 16 19.4 / 18.9 / 24.8, k = 64 22.0 / 23.9 / 33.8, k = 256 22.7 / 24.7 / 34.9 us

@@ -648,7 +648,7 @@ __device__ __forceinline__ void vec_bucket(const KParams& p, const PointTable* T
     // quantize-dequantize consumes only the LEVEL of u, so the bucket-invariant division form is exact there (qd_common.h);
     // wave-uniform choice: every bucket of the wave must be in the proven range.  The transform loop is instantiated per
     // (variant, division form) and chosen ONCE per bucket: with the flags tested inside the loop the compiler no longer
-    // unswitched it and the kernel executed 37.9 M instead of 33.9 M VALU wave-instructions (profiles/r02_sq_counters.txt).
+    // unswitched it and the kernel executed 37.9 M instead of 33.9 M VALU wave-instructions (docs/history/profiles/r02_sq_counters.txt).
     const bool fast = MODE == MODE_QDQ && !__any(!fastdiv_ok(a));
     if (MODE == MODE_SCALE) {
         unsigned key = 0xFFFFFFFFu;
@@ -1703,7 +1703,7 @@ inline void geometry(int64_t n, int64_t bucket, int64_t& nb, int64_t& row) {
 inline int num_cus() { return device_cus(); }
 
 inline int grid_cap() {
-    // Measured on MI355X (tools/tune_k1.py, profiles/r01_tune.txt): one wave-tile per wave (no grid-stride
+    // Measured on MI355X (tools/tune_k1.py, docs/history/profiles/r01_tune.txt): one wave-tile per wave (no grid-stride
     // reuse) streams fastest -- 85.9 us vs 97 us at 2048 persistent blocks for the 64 Mi-element
     // headline tensor -- so the cap only bounds the grid dimension.
 #ifdef QD_TUNING        // launch-geometry experiments only (build with -DQD_TUNING): QD_GRID_CAP=<blocks>
@@ -1769,7 +1769,7 @@ int launch_bucketed(KParams& p, hipStream_t st) {
         // one wave per bucket, any size (k_bucket_wave_any): sizes above 512, and sizes from 448 that are not a multiple of 4
         // (multiples of 4 up to 512 stay with the chunk kernel: 300 -> 90 us against 127 us here; the vector sizes 512 /
         // 1024 / 2048 were taken above).  The lane -> float4 mapping starts at the 128-byte line (32 elements) at or below
-        // the bucket (measured against 16- and 64-element boundaries: profiles/r02_tune_kernels.txt).
+        // the bucket (measured against 16- and 64-element boundaries: docs/history/profiles/r02_tune_kernels.txt).
         const bool mult4 = (p.row & 3) == 0;
         constexpr int al = 32;
         const bool line_ok = (p.row * 4) % (al * 4) == 0;                        // every bucket starts on the boundary anyway
@@ -1917,7 +1917,7 @@ int fused_capacity() {                                         // blocks of k_si
 }
 // one epoch sequence for ALL instantiations, 64 bits: a tag never repeats on a slot set (epoch 0 = a never-written slot)
 std::atomic<uint64_t> next_launch{1};
-// Measured on MI355X (profiles/r02_k1g_fused.txt): a device-scope round trip costs 1.5-2 us, so the barrier adds ~3.5 us
+// Measured on MI355X (docs/history/profiles/r02_k1g_fused.txt): a device-scope round trip costs 1.5-2 us, so the barrier adds ~3.5 us
 // to a kernel -- about what a kernel boundary costs -- and the load and store phases of the register-resident kernel do
 // not overlap, while the three-launch path's second read is served by the 256 MiB Infinity Cache.  One launch wins only
 // where the call is launch-bound: up to 1 Mi elements (GPU time 7.8 vs 9.7 us at 0.1 M, 10.8 vs 10.9 at 0.8 M; one host

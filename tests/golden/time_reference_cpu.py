@@ -2,7 +2,7 @@
 """Authoring-container only (needs /root/reference): time the REFERENCE's own uniformQuantization on the headline
 workload next to the two CPU ports that bench.py times on the GPU box (oracle/qd_oracle.c, oracle/torch_port.py), on
 the same cores.  The GPU box has no /root/reference, so bench.py's cpu_baseline is kind "port"; this file calibrates
-the ports against the real thing on identical hardware.  Writes profiles/r01_reference_cpu_timing.json."""
+the ports against the real thing on identical hardware.  Writes docs/history/profiles/r01_reference_cpu_timing.json."""
 import json
 import os
 import sys

@@ -945,9 +945,9 @@ def test_pack_unpack_roundtrip(s, bits):
         assert pk.nbytes == (n * bits + 7) // 8 + 8 * (1 if (bucket is None or n < bucket) else -(-n // bucket))
 
 
-def test_unpack_wide_and_narrow_forms_agree():
-    """qd_unpack_uniform_f32 decodes whole 1 KiB chunks of the packed stream with 16-byte loads (k_unpack_wide) and the rest --
-    or everything, when the packed stream or the output is not 16-byte aligned -- four elements per lane (k_unpack): same bits."""
+def test_unpack_at_every_alignment():
+    """qd_unpack_uniform_f32 on outputs / packed streams that start 4 bytes into a 16-byte granule, sizes around whole KiB of
+    packed data: the same bits as the aligned call and as uniformQuantization."""
     from quantized_distillation_amd import codec
     lib = _lib.load()
     rng = np.random.RandomState(11)

@@ -67,6 +67,19 @@ record('PK pack 4-bit', 'k_pack_vec<16, 4, 4>', int(4.5 * N), lambda i: keep.app
 pk = codec.pack_uniform(xs[0], 16, 256)
 counts['k_pack_vec<16, 4, 4>'] += 1
 record('UPK unpack 4-bit', 'k_unpack<4>', int(4.5 * N), lambda i: keep.append(pk.unpack()))
+lev8 = [torch.randint(0, 16, (N,), dtype=torch.uint8, device=dev) for _ in range(3)]
+record('LV8 levels only (qd_uniform_f32 with q == NULL)', 'k_pack_vec<16, 4, 8>', 5 * N,
+       lambda i: keep.append(codec.level_histogram(xs[i], 16, 256)))
+sfh = quantization.ScalingFunction('linear', False, False, 256)
+uu = sfh.scale_down(xs[1]).view(-1)
+counts['k_bucket_vec<1, 16, 4, 1>'] = counts.get('k_bucket_vec<1, 16, 4, 1>', 0) + 1
+import numpy as np  # noqa: E402
+import quantization.help_functions as qhf  # noqa: E402
+edges = torch.from_numpy(qhf._digitize_edges(16, 1e-5)).to(dev)
+record('DGH digitize + histogram of the re-scaled tensor (Huffman accounting)', 'k_hist_sym<0>', 4 * N,
+       lambda i: keep.append(qhf._device_counts('digitize', uu, 16, edges)))
+idx64 = torch.randint(0, 4, (N,), device=dev)
+record('I64 histogram of int64 point indices', 'k_hist_sym<1>', 8 * N, lambda i: keep.append(qhf._device_counts('index', idx64, 256)))
 # round 3: the calls with a side output at the bucket sizes of the chunk kernels
 # (K5 -- the pre-processed forward -- is the float4 stream kernel at every bucket size: <true> when a float4 can straddle buckets)
 for b, kern4, kern5 in ((100, 'k_bucket_chunk<2, 8>', 'k_nearest_prescaled_stream<false>'), (33, 'k_bucket_chunk_any<2, 8>', 'k_nearest_prescaled_stream<true>'),
