@@ -198,7 +198,7 @@ def cpu_distill_baseline(refq=None, steps=200, warmup=3, batch=50):
 from harness.dpbench import XGMI_PEAK_GBPS, dp_report, event_ms, flat_dp, timed_steps  # noqa: E402,F401
 
 
-def distill_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=100, warmup=20, per_gpu_batch=50):
+def distill_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=100, warmup=20, per_gpu_batch=50, repetitions=7):
     """Second half of BASELINE.json's metric: distilled-training steps/sec on synthetic
     CIFAR10-shaped data (configs[1]: ConvolForwardNet student, 4-bit uniform quantization, bucket
     256, pure STE), data parallel over the ranks with one RCCL all-reduce of the flat gradient
@@ -247,7 +247,7 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=100
     # moves from repetition to repetition on one box (profiles/r03_distill_spread.txt).  So: REPS repetitions of `steps`
     # steps per mode, INTERLEAVED (multi, per_tensor, multi, ...) so that drift hits both alike; the MEDIAN is reported,
     # every repetition is listed, and the two modes are only called different when their ranges do not overlap.
-    REPS = 7
+    REPS = repetitions
     reps = {m: [] for m in modes}
     for _rep in range(REPS):
         for mode in modes:
@@ -491,6 +491,7 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 PMC passes that measure the HBM traffic of the headline kernel')
     ap.add_argument('--deadline-s', type=float, default=1500.0,
                     help='after this many seconds rank 0 prints the line with what has been measured so far and the run ends')
+    ap.add_argument('--quick', action='store_true', help='short steps/sec legs (a few steps, two repetitions): for exercising the flow, not for numbers')
     ap.add_argument('--pmc-slice', action='store_true', help=argparse.SUPPRESS)       # child mode of measure_pmc_traffic()
     args = ap.parse_args()
     if args.pmc_slice:
@@ -521,6 +522,12 @@ def main():
                          % (args.gpus, world, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    # QD_BENCH_BACKEND=gloo + QD_BENCH_ONE_GPU=1: the WHOLE multi-rank flow (per-leg agreement, the data-parallel report with
+    # rank 0 alone, the closing barriers) on a one-GPU box -- every rank on device 0, collectives through gloo instead of RCCL
+    # (tests/test_hip_bench_ranks.py).  The driver never sets these.
+    backend = os.environ.get('QD_BENCH_BACKEND', 'nccl')
+    if os.environ.get('QD_BENCH_ONE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
@@ -528,7 +535,10 @@ def main():
     rccl_error = None
     legs.rccl_env_defaults()                 # a timed-out collective raises on the waiting ranks instead of ending them
     if launch.under_launcher():
-        dist.init_process_group('nccl', device_id=dev, timeout=legs.data_timeout())        # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev, timeout=legs.data_timeout())    # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend, timeout=legs.data_timeout())
     else:
         # single process: still a (one-rank) RCCL group, and QD_FORCE_DIST=1 makes the harness issue its
         # collectives in it, so that the all-reduce path of the steps/sec legs is executed and timed on this box
@@ -635,6 +645,27 @@ def main():
     copy_gbps = ALGO_BYTES_PER_ELEM * N_ELEM * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
     del ya
 
+    # What the call would cost a caller that hands over HOST buffers (the boundary takes device tensors: this is a note, never
+    # `value`): pinned host -> device, quantize, device -> pinned host, 3 repetitions on one stream.
+    pcie_gbps = None
+    if rank == 0 and n_gpus == 1:
+        try:
+            hx, hq = x_host.pin_memory(), torch.empty(N_ELEM).pin_memory()
+            xd = torch.empty_like(xs[0])
+            ts = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t_a = time.perf_counter()
+                xd.copy_(hx, non_blocking=True)
+                q_, _sf = quantization.uniformQuantization(xd, LEVELS, bucket_size=BUCKET)
+                hq.copy_(q_, non_blocking=True)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t_a)
+            pcie_gbps = ALGO_BYTES_PER_ELEM * N_ELEM / min(ts[1:]) / 1e9
+            del hx, hq, xd, q_
+        except Exception as e:                                    # noqa: BLE001 -- a note, not the measurement
+            sys.stderr.write('pcie-inclusive note skipped: %s\n' % e)
+
     bytes_per_launch = ALGO_BYTES_PER_ELEM * N_ELEM
     kernel_us = event_ms_total * 1e3 / args.steps
     achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
@@ -652,6 +683,7 @@ def main():
         'extended_avg_launch_us': round(ext_us, 3),
         'avg_launch_us': round(kernel_us, 3), 'algorithmic_bytes_per_launch': bytes_per_launch,
         'timing': 'HIP events on the launch stream around the %d timed launches (includes inter-launch gaps)' % args.steps,
+        'pcie_inclusive_GBps_note': round(pcie_gbps, 1) if pcie_gbps else None,   # host buffer -> HBM -> quantize -> host buffer (never `value`)
         'torch_d2d_copy_GBps': round(copy_gbps, 1),      # torch's own copy of the same bytes, same box (a hand-written NT copy reaches 6.3-6.5 TB/s: docs/history/profiles/r01_kbench.txt)
     }
     line.update({
@@ -668,7 +700,8 @@ def main():
         },
         'cpu_baseline': None, 'distill': None,
         'parity_bit_exact_vs_oracle': None, 'parity_bit_exact_vs_reference': None,
-        'rccl_world_size': rccl_world_size, 'rccl_error': rccl_error, 'device': torch.cuda.get_device_name(dev),
+        'rccl_world_size': rccl_world_size, 'rccl_error': rccl_error, 'collective_backend': backend,
+        'device': torch.cuda.get_device_name(dev),
         'roofline': roofline,                             # last: the driver keeps the tail of the line
     })
 
@@ -717,18 +750,20 @@ def main():
     if not args.no_distill:
         distill = {}
         line['distill'] = distill
-        distill['cifar_student'] = runner.run('cifar_student', distill_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier)
+        quick = dict(steps=3, warmup=2, reps=2) if args.quick else {}
+        distill['cifar_student'] = runner.run('cifar_student', distill_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier,
+                                              **(dict(steps=20, warmup=5, repetitions=2) if args.quick else {}))
         torch.cuda.empty_cache()
         if not args.no_diffquant:
-            distill['diffquant_wrn'] = runner.run('diffquant_wrn', diffquant_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier)
+            distill['diffquant_wrn'] = runner.run('diffquant_wrn', diffquant_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier, **quick)
             torch.cuda.empty_cache()
         # configs[3] is quoted on 8 GPUs and configs[4] on 4; both fit one GPU, so they are timed at every N
         # (weak scaling: per-GPU batch fixed) and the driver's --gpus 8 / --gpus 4 runs give BASELINE's placements
         if not args.no_dp_configs:
             distill['imagenet_resnet18k_dp'] = runner.run('imagenet_resnet18k_dp', dp_config_steps_per_sec, 'imagenet', dev, rank, n_gpus,
-                                                          distributed, runner.barrier)
+                                                          distributed, runner.barrier, **quick)
             torch.cuda.empty_cache()
-            distill['nmt_lstm_dp'] = runner.run('nmt_lstm_dp', dp_config_steps_per_sec, 'nmt', dev, rank, n_gpus, distributed, runner.barrier)
+            distill['nmt_lstm_dp'] = runner.run('nmt_lstm_dp', dp_config_steps_per_sec, 'nmt', dev, rank, n_gpus, distributed, runner.barrier, **quick)
         if runner.history:
             distill['legs_failed'] = [{'leg': n, 'ranks': r} for n, r in runner.history]
 

@@ -1,0 +1,50 @@
+"""bench.py's multi-rank flow on a one-GPU box: two ranks on device 0, collectives through gloo (QD_BENCH_BACKEND=gloo,
+QD_BENCH_ONE_GPU=1) -- everything the driver's `--gpus N` run goes through except RCCL itself: the launcher, the per-leg
+agreement over the control group, the data-parallel report with rank 0 running alone while the others wait, the closing
+barriers, ONE JSON line from rank 0 with the contract keys and the data-parallel keys of every steps/sec leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from harness import launch
+from harness.dpbench import DP_KEYS
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_quick_run_end_to_end():
+    env = dict(os.environ, QD_BENCH_BACKEND='gloo', QD_BENCH_ONE_GPU='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = launch.launcher_command(os.path.join(ROOT, 'bench.py'), 2, ['--gpus', '2', '--steps', '5', '--warmup', '2', '--quick', '--no-cpu-baseline',
+                                                                       '--no-pmc', '--no-kernels', '--precondition-s', '0.05'])
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['scaling'] == 'weak' and d['collective_backend'] == 'gloo'
+    assert d['value'] > 0 and d['roofline']['frac'] > 0
+    assert abs(d['value'] - 2 * 8 * d['config']['n_elements_per_gpu'] / (d['ms_per_step'] * 1e-3) / 1e9) <= 2e-3 * d['value']
+    legs_ = d['distill']
+    assert 'legs_failed' not in legs_, legs_.get('legs_failed')
+    for name in ('diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp'):
+        leg = legs_[name]
+        assert 'error' not in leg and 'skipped' not in leg, (name, leg)
+        for k in DP_KEYS:
+            assert k in leg, (name, k)
+        assert leg['n_gpus'] == 2 and leg['global_batch'] == 2 * leg['per_gpu_batch']
+        assert leg['rank_ms_per_step']['min'] <= leg['rank_ms_per_step']['max']
+        assert leg['busbw_GBps'] > 0                       # 2 (N-1)/N x bytes / t with N = 2
+    dp1 = legs_['cifar_student']['dp']
+    for k in DP_KEYS:
+        assert k in dp1, k
+    # the scalars the driver's record keeps
+    r = d['roofline']
+    assert isinstance(r['steps_cfg1'], str) and 'multi' in r['steps_cfg1']
+    for key in ('dp_cfg1', 'dp_cfg2_wrn_diffquant', 'dp_cfg3_imagenet', 'dp_cfg4_nmt'):
+        assert isinstance(r[key], str) and len(r[key]) <= 118 and 'N=2' in r[key], (key, r.get(key))
