@@ -491,6 +491,7 @@ def main():
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 PMC passes that measure the HBM traffic of the headline kernel')
     ap.add_argument('--deadline-s', type=float, default=1500.0,
                     help='after this many seconds rank 0 prints the line with what has been measured so far and the run ends')
+    ap.add_argument('--skip-legs', default='', help='comma-separated steps/sec legs to leave out (cifar_student, diffquant_wrn, imagenet_resnet18k_dp, nmt_lstm_dp)')
     ap.add_argument('--quick', action='store_true', help='short steps/sec legs (a few steps, two repetitions): for exercising the flow, not for numbers')
     ap.add_argument('--pmc-slice', action='store_true', help=argparse.SUPPRESS)       # child mode of measure_pmc_traffic()
     args = ap.parse_args()
@@ -751,18 +752,21 @@ def main():
         distill = {}
         line['distill'] = distill
         quick = dict(steps=3, warmup=2, reps=2) if args.quick else {}
-        distill['cifar_student'] = runner.run('cifar_student', distill_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier,
-                                              **(dict(steps=20, warmup=5, repetitions=2) if args.quick else {}))
-        torch.cuda.empty_cache()
-        if not args.no_diffquant:
+        skip = set(x for x in args.skip_legs.split(',') if x)
+        if 'cifar_student' not in skip:
+            distill['cifar_student'] = runner.run('cifar_student', distill_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier,
+                                                  **(dict(steps=20, warmup=5, repetitions=2) if args.quick else {}))
+            torch.cuda.empty_cache()
+        if not args.no_diffquant and 'diffquant_wrn' not in skip:
             distill['diffquant_wrn'] = runner.run('diffquant_wrn', diffquant_steps_per_sec, dev, rank, n_gpus, distributed, runner.barrier, **quick)
             torch.cuda.empty_cache()
         # configs[3] is quoted on 8 GPUs and configs[4] on 4; both fit one GPU, so they are timed at every N
         # (weak scaling: per-GPU batch fixed) and the driver's --gpus 8 / --gpus 4 runs give BASELINE's placements
-        if not args.no_dp_configs:
+        if not args.no_dp_configs and 'imagenet_resnet18k_dp' not in skip:
             distill['imagenet_resnet18k_dp'] = runner.run('imagenet_resnet18k_dp', dp_config_steps_per_sec, 'imagenet', dev, rank, n_gpus,
                                                           distributed, runner.barrier, **quick)
             torch.cuda.empty_cache()
+        if not args.no_dp_configs and 'nmt_lstm_dp' not in skip:
             distill['nmt_lstm_dp'] = runner.run('nmt_lstm_dp', dp_config_steps_per_sec, 'nmt', dev, rank, n_gpus, distributed, runner.barrier, **quick)
         if runner.history:
             distill['legs_failed'] = [{'leg': n, 'ranks': r} for n, r in runner.history]

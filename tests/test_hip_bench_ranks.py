@@ -21,7 +21,8 @@ def test_two_ranks_quick_run_end_to_end():
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     cmd = launch.launcher_command(os.path.join(ROOT, 'bench.py'), 2, ['--gpus', '2', '--steps', '5', '--warmup', '2', '--quick', '--no-cpu-baseline',
-                                                                       '--no-pmc', '--no-kernels', '--precondition-s', '0.05'])
+                                                                       '--no-pmc', '--no-kernels', '--precondition-s', '0.05',
+                                                                       '--skip-legs', 'diffquant_wrn,nmt_lstm_dp'])     # (all four legs: tools/gpu_session.sh ranks2)
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
@@ -32,7 +33,8 @@ def test_two_ranks_quick_run_end_to_end():
     assert abs(d['value'] - 2 * 8 * d['config']['n_elements_per_gpu'] / (d['ms_per_step'] * 1e-3) / 1e9) <= 2e-3 * d['value']
     legs_ = d['distill']
     assert 'legs_failed' not in legs_, legs_.get('legs_failed')
-    for name in ('diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp'):
+    assert 'diffquant_wrn' not in legs_ and 'nmt_lstm_dp' not in legs_
+    for name in ('imagenet_resnet18k_dp',):
         leg = legs_[name]
         assert 'error' not in leg and 'skipped' not in leg, (name, leg)
         for k in DP_KEYS:
@@ -46,5 +48,5 @@ def test_two_ranks_quick_run_end_to_end():
     # the scalars the driver's record keeps
     r = d['roofline']
     assert isinstance(r['steps_cfg1'], str) and 'multi' in r['steps_cfg1']
-    for key in ('dp_cfg1', 'dp_cfg2_wrn_diffquant', 'dp_cfg3_imagenet', 'dp_cfg4_nmt'):
+    for key in ('dp_cfg1', 'dp_cfg3_imagenet'):
         assert isinstance(r[key], str) and len(r[key]) <= 118 and 'N=2' in r[key], (key, r.get(key))

@@ -16,6 +16,8 @@
 #   side       tools/side_output_probe.py (calls with index / level side outputs at every bucket-size family; SIDE_ARGS)
 #   spread     tools/distill_spread_probe.py: repetition-to-repetition spread of the configs[1] step, with a kernel trace
 #   stack      ROCm / driver / torch versions of the box
+#   torchrun   bench.py under torch.distributed.run with one rank;  ranks2: two ranks on this one GPU through gloo
+#   kprof      tools/bench_kernels.py --no-sweeps under rocprofv3 --kernel-trace --stats
 #   coverage   tools/launch_coverage.py --run: the GPU suite under rocprofv3 --kernel-trace --stats, shipped kernels never launched
 #   dispatch   tools/dispatch_map.py --trace: call geometry -> kernel map
 set +e
@@ -30,7 +32,17 @@ for step in "$@"; do
     smoke)   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log ;;
     tests)   rm -f gpurun_out/reduction_error.jsonl; timeout 3000 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.log; python tools/summarize_reduction_error.py > gpurun_out/reduction_error.txt 2>&1; cat gpurun_out/reduction_error.txt ;;
     bench)   timeout 1500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-900 gpurun_out/bench.json
-             timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-distill 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('driver flags:', d['value'], d['roofline']['avg_launch_us'], d['roofline']['frac'])" ;;
+             timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_flags.json 2> gpurun_out/bench_driver_flags.err; python -c "import json; d=json.loads(open('gpurun_out/bench_driver_flags.json').read().strip().splitlines()[-1]); print('driver flags:', d['value'], d['roofline']['avg_launch_us'], d['roofline']['frac'], len(d['roofline'].get('kernels') or []), 'kernel rows')" ;;
+    torchrun) # the way the driver starts N > 1, with one rank: env rendezvous, RCCL group from the launcher's environment
+             timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > gpurun_out/bench_torchrun.json 2> gpurun_out/bench_torchrun.err; echo "torchrun rc=$?"; tail -1 gpurun_out/bench_torchrun.json | cut -c1-300 ;;
+    ranks2)  # the whole multi-rank flow on this one GPU: two ranks on device 0, collectives through gloo (bench.py QD_BENCH_BACKEND)
+             QD_BENCH_BACKEND=gloo QD_BENCH_ONE_GPU=1 timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-kernels > gpurun_out/bench_two_ranks_one_gpu.json 2> gpurun_out/bench_two_ranks_one_gpu.err; echo "ranks2 rc=$?"; tail -1 gpurun_out/bench_two_ranks_one_gpu.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['n_gpus'], d['collective_backend']); [print(k, r[k]) for k in r if k.startswith('dp_') or k.startswith('steps_')]" ;;
+    kprof)   # the kernel rows under rocprofv3: the per-kernel average durations next to the HIP-event figures
+             rm -rf gpurun_out/kprof_stats
+             (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kprof_stats -o kernels -- python $R/tools/bench_kernels.py 26 --no-sweeps > $R/gpurun_out/kernels_under_rocprof.txt 2> $R/gpurun_out/kprof.err); echo "kprof rc=$?"
+             find gpurun_out/kprof_stats -name '*kernel_stats.csv' -exec cp {} gpurun_out/kernels_rocprof_stats.csv \;
+             find gpurun_out/kprof_stats -name '*.csv' -size +4M -delete
+             head -12 gpurun_out/kernels_rocprof_stats.csv | cut -c1-200 ;;
     prof)    rm -rf gpurun_out/prof_stats gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
              (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o bench -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-distill --no-pmc > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "stats rc=$?"
              for c in FETCH_SIZE WRITE_SIZE; do

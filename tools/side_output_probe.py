@@ -17,7 +17,7 @@ import torch  # noqa: E402
 import quantization  # noqa: E402
 from quantized_distillation_amd import _lib  # noqa: E402
 
-if os.environ.get('QD_LIB'):                      # A/B on one box: another build of the library (tools/build_rev_lib.py)
+if os.environ.get('QD_LIB'):                      # A/B on one box: another build of the library (docs/history/tools/build_rev_lib.py)
     _lib.LIB_PATH = os.environ['QD_LIB']
 
 N = 1 << 26
