@@ -193,8 +193,8 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
     pk = [codec.pack_uniform(xs[j], 16, 256) for j in range(R)]
     add('UPK unpack 4-bit -> fp32 b256', 'k_unpack<4>', lambda i: keep(i, pk[i % R].unpack()), 4.5, N)
     del pks, pk
-    add('LVH level histogram of x, s=16 b256', 'k_pack_vec<16,4,8>+k_hist_atomic<2>+k_hist_fold', lambda i: codec.level_histogram(xs[i % R], 16, 256), 5, N,
-        note='levels only (no q): 4 B read + 1 B written, + 1 B read by the count')
+    add('LVH level histogram of x, s=16 b256', 'k_level_hist_vec<16,4>+k_hist_fold', lambda i: codec.level_histogram(xs[i % R], 16, 256), 4, N,
+        note='levels counted in the kernel that computes them: 4 B read, nothing written')
     live[:] = [None] * R
     del xs
     NH = 1 << hist_log2n

@@ -54,7 +54,8 @@ extern "C" {
 
 /* Library identification: ABI version (bumped on every change of an entry point's meaning or signature) and target arch.
  * History: 1 = rounds 1-3; 2 = qd_nearest_point_f32 accepts q == NULL (indices only), qd_uniform_f32 accepts q == NULL with
- * level_idx (levels only), qd_selftest_div_invariant, qd_digitize_histogram_f32 / qd_histogram_i64 added, 4-byte data alignment.
+ * level_idx (levels only), qd_selftest_div_invariant, qd_digitize_histogram_f32 / qd_histogram_i64 / qd_level_histogram_f32
+ * added, 4-byte data alignment.
  * The Python binding and _qd_glue.so compare the version THEY were built for with the library's. */
 #define QD_ABI_VERSION 2
 int qd_abi_version(void);
@@ -248,6 +249,13 @@ int qd_unpack_uniform_f32(const uint8_t* packed, int64_t n, int64_t bucket, int 
 int qd_histogram_u8(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* stream);
 int qd_histogram_u8_ws(const uint8_t* idx, int64_t n, int k, uint64_t* hist, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* qd_level_histogram_f32: hist[j] = number of elements of x whose quantization level (levels per bucket, as qd_uniform_f32
+ * computes it) is j, j < levels <= 256 -- in ONE pass, 4 B read per element: the level indices are counted in the kernel that
+ * computes them and never written.  bucket in {64 ... 2048}, x 16-byte aligned (QD_ERR_UNSUPPORTED otherwise: callers then
+ * write the levels with qd_uniform_f32 and count them with qd_histogram_u8_ws).  Elements of a bucket that holds a NaN count as
+ * level 0 (what the uint8 level output stores for them).  workspace as for qd_histogram_u8_ws. */
+int qd_level_histogram_f32(const float* x, int64_t n, int64_t bucket, int levels, uint64_t* hist, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* The two histograms get_huffman_encoding_mean_bit_length needs when it runs on the device (quantization/help_functions.py:
  * 175-232; only the counters cross PCIe instead of every quantized tensor):
  * qd_digitize_histogram_f32: hist[c] = #{ i : #{ j < m : edges[j] <= v[i] } == c }, c = 0 .. m (hist has m + 1 entries; a NaN

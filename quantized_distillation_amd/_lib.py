@@ -78,6 +78,7 @@ SIGNATURES = {
     'qd_unpack_uniform_f32': (c_int, [c_p, i64, i64, c_int, c_int, c_f, c_f, c_f, c_p]),
     'qd_histogram_u8': (c_int, [c_p, i64, c_int, c_p, c_p]),
     'qd_histogram_u8_ws': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),
+    'qd_level_histogram_f32': (c_int, [c_f, i64, i64, c_int, c_p, c_p, c_size, c_p]),
     'qd_digitize_histogram_f32': (c_int, [c_f, i64, c_p, c_int, c_p, c_p, c_size, c_p]),
     'qd_histogram_i64': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),
     'qd_order_stats_workspace_bytes': (ctypes.c_size_t, [c_int]),

@@ -100,28 +100,30 @@ def histogram_u8(idx, k):
 
 
 def level_histogram(tensor, s, bucket_size=None):
-    """Histogram of the quantization levels of `tensor` (s <= 256), computed on the device: the level indices are written by
-    the quantize kernel in its levels-only form (qd_uniform_f32 with q == NULL: 4 B read + 1 B written per element, no
-    throw-away q), then one counting pass (1 B read).  Bucket geometries outside that form (bucket_size None or not one of
-    64 ... 2048, a misaligned view) take the q-writing form of the same kernel."""
+    """Histogram of the quantization levels of `tensor` (s <= 256), computed on the device.  At the vector bucket sizes
+    (64 ... 2048) ONE pass over the tensor counts the levels in the kernel that computes them (qd_level_histogram_f32: 4 B read
+    per element, nothing written but s counters).  Other bucket geometries (bucket_size None, any other size, a misaligned
+    view) write the uint8 levels with the quantize kernel and count those."""
     _lib.require_device_f32(tensor)
     x = tensor.contiguous().view(-1)
     if _lib.on_other_device(x):
         with torch.cuda.device(x.device):
             return level_histogram(tensor, s, bucket_size)
     n = x.numel()
+    lib = _lib.load()
+    ws = _lib.workspace(x.device)
+    bucket = 0 if bucket_size is None else bucket_size
+    hist = torch.empty(int(s), dtype=torch.int64, device=x.device)
+    rc = lib.qd_level_histogram_f32(x.data_ptr(), n, bucket, int(s), hist.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    if rc == 0:
+        return hist
+    if rc != QD_ERR_UNSUPPORTED:
+        _lib.check(rc)
     lev = torch.empty(n, dtype=torch.uint8, device=x.device)
     if n > 0:
-        lib = _lib.load()
-        ws = _lib.workspace(x.device)
-        bucket = 0 if bucket_size is None else bucket_size
-        rc = lib.qd_uniform_f32(x.data_ptr(), None, n, bucket, int(s), None, None, lev.data_ptr(), None, 0, 0.0, 0, 0,
-                                ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        if rc == QD_ERR_UNSUPPORTED:
-            q = torch.empty_like(x)
-            rc = lib.qd_uniform_f32(x.data_ptr(), q.data_ptr(), n, bucket, int(s), None, None, lev.data_ptr(), None, 0, 0.0, 0, 0,
-                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        _lib.check(rc)
+        q = torch.empty_like(x)
+        _lib.check(lib.qd_uniform_f32(x.data_ptr(), q.data_ptr(), n, bucket, int(s), None, None, lev.data_ptr(), None, 0, 0.0, 0, 0,
+                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
     return histogram_u8(lev, s)
 
 

@@ -429,6 +429,74 @@ __global__ __launch_bounds__(256) void k_hist_sym(const void* data, int64_t n, i
     }
 }
 
+// Level histogram of x in ONE pass (4 B read per element, nothing written but the counters): the quantize half of
+// k_pack_vec -- a bucket in registers, min / max by DPP or wave reduction, level = rint((x - beta) / alpha * (s - 1)) --
+// feeding the [levels + 1][32] LDS counter table of k_hist_atomic instead of a store.  What codec.level_histogram (the
+// Huffman accounting of a model in its own packed format) needs: the level indices themselves never reach memory.
+// Persistent grid: the table is zeroed and flushed once per block.  The short last bucket is done by block 0's first wave.
+template <int LPB, int V>
+__global__ __launch_bounds__(256) void k_level_hist_vec(const float* x, int64_t nvec, int64_t n, float sm1, int levels,
+                                                        unsigned long long* partial /* [levels][gridDim.x] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hist_lds[];
+    uint32_t* cnt = (uint32_t*)hist_lds;                                   // [levels + 1][32], row `levels` = dummy (NaN buckets)
+    constexpr int BPW = 64 / LPB;
+    constexpr int ROW = LPB * V * 4;
+    for (int j = threadIdx.x; j < (levels + 1) * 32; j += 256) cnt[j] = 0;
+    __syncthreads();
+    uint32_t* col = cnt + (threadIdx.x & 31);
+    const float top = (float)levels;
+    auto bump = [&](float lev) {                                           // lev: an integer in [0, levels - 1]; NaN (a bucket that holds one) counts as
+        const uint32_t li = (lev >= 0.0f && lev < top) ? (uint32_t)(int)lev : 0u;      // level 0, which is what the uint8 level output stores for it
+        __hip_atomic_fetch_add(col + li * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPB, l = lane % LPB;
+    const int64_t wave = uniform_wave_index();
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ntiles = (nvec + BPW - 1) / BPW;
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+        const int64_t bkt = t * BPW + sub;
+        if (bkt >= nvec) continue;
+        const int64_t e0 = bkt * ROW + (int64_t)l * 4;
+        f4 v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load((const f4*)(x + e0) + j * LPB);
+        float mn = pmin4(v[0]), mx = pmax4(v[0]);                          // NaN-propagating, as torch's min / max
+#pragma unroll
+        for (int j = 1; j < V; ++j) { mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j])); }
+        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); } else { mn = wave_min(mn); mx = wave_max(mx); }
+        float a, b;
+        alpha_beta(mn, mx, a, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float lev[4];
+            qdq(v[j].x, a, b, sm1, 0.0f, lev[0]);
+            qdq(v[j].y, a, b, sm1, 0.0f, lev[1]);
+            qdq(v[j].z, a, b, sm1, 0.0f, lev[2]);
+            qdq(v[j].w, a, b, sm1, 0.0f, lev[3]);
+            bump(lev[0]); bump(lev[1]); bump(lev[2]); bump(lev[3]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64 && nvec * ROW < n) {           // the short last bucket [nvec * ROW, n)
+        const int64_t lo = nvec * ROW;
+        float mn = INFINITY, mx = -INFINITY;
+        bool nan = false;
+        for (int64_t i = lo + lane; i < n; i += 64) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); nan |= (v != v); }
+        mn = wave_min(mn); mx = wave_max(mx);
+        if (group_any<64>(nan)) { mn = NAN; mx = NAN; }
+        float a, b;
+        alpha_beta(mn, mx, a, b);
+        for (int64_t i = lo + lane; i < n; i += 64) { float lev; qdq(x[i], a, b, sm1, 0.0f, lev); bump(lev); }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < levels; j += 256) {
+        unsigned long long total = 0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) total += cnt[j * 32 + ((c + j) & 31)];
+        partial[(size_t)j * gridDim.x + blockIdx.x] = total;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_zero_u64(unsigned long long* p, int n) {
     for (int i = threadIdx.x; i < n; i += 256) p[i] = 0ull;
 }
@@ -609,6 +677,45 @@ int launch_hist_sym(const void* data, int64_t n, int nrows, const double* edges,
 }  // namespace
 
 extern "C" {
+
+int qd_level_histogram_f32(const float* x, int64_t n, int64_t bucket, int levels, uint64_t* hist, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (n < 0 || levels < 2 || levels > 256 || !hist || (n > 0 && !x)) return QD_ERR_INVALID_ARGUMENT;
+    if (bucket != 64 && bucket != 128 && bucket != 256 && bucket != 512 && bucket != 1024 && bucket != 2048) return QD_ERR_UNSUPPORTED;
+    if (((uintptr_t)x) & 15) return QD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_zero_u64, dim3(1), dim3(256), 0, st, (unsigned long long*)hist, levels);
+        return (int)hipGetLastError();
+    }
+    if (!workspace || (((uintptr_t)workspace) & 7)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    const int64_t nfull = n / bucket;
+    const size_t lds = (size_t)(levels + 1) * 32 * sizeof(uint32_t);
+    const float sm1 = (float)(levels - 1);
+#define QD_LH(LPB, V)                                                                                                 \
+    {                                                                                                                 \
+        const int64_t tiles = (nfull + (64 / LPB) - 1) / (64 / LPB);                                                  \
+        int blocks = blocks_for(tiles > 0 ? tiles : 1, 4, device_cus() * 4);                                          \
+        const size_t room = workspace_bytes / ((size_t)levels * sizeof(unsigned long long));                          \
+        if ((size_t)blocks > room) blocks = (int)room;                                                                \
+        if (blocks < 1) return QD_ERR_WORKSPACE_TOO_SMALL;                                                            \
+        if (n > ((int64_t)blocks << 31)) return QD_ERR_UNSUPPORTED;        /* a uint32 counter per block and level */  \
+        hipLaunchKernelGGL((k_level_hist_vec<LPB, V>), dim3(blocks), dim3(256), lds, st, x, nfull, n, sm1, levels,    \
+                           (unsigned long long*)workspace);                                                           \
+        hipLaunchKernelGGL(k_hist_fold, dim3(levels), dim3(256), 0, st, (const unsigned long long*)workspace, blocks, \
+                           (unsigned long long*)hist, 0);                                                             \
+    }
+    switch (bucket) {
+        case 64: QD_LH(16, 1) break;
+        case 128: QD_LH(16, 2) break;
+        case 256: QD_LH(16, 4) break;
+        case 512: QD_LH(64, 2) break;
+        case 1024: QD_LH(64, 4) break;
+        default: QD_LH(64, 8) break;
+    }
+#undef QD_LH
+    return (int)hipGetLastError();
+}
 
 int qd_digitize_histogram_f32(const float* v, int64_t n, const double* edges, int m, uint64_t* hist, void* workspace,
                               size_t workspace_bytes, void* stream) {

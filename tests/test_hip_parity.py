@@ -977,10 +977,21 @@ def test_unpack_at_every_alignment():
 def test_level_histogram_and_device_huffman(golden_misc):
     from quantized_distillation_amd import codec
     rng = np.random.RandomState(1)
-    for n, s, bucket in [(100003, 16, 256), (1 << 20, 4, None), (5000, 256, 256), (77, 2, 256)]:
+    for n, s, bucket in [(100003, 16, 256), (1 << 20, 4, None), (5000, 256, 256), (77, 2, 256), (64 * 3001 + 9, 16, 64), (128 * 700, 4, 128),
+                         (512 * 333 + 100, 256, 512), (1024 * 100 + 1, 16, 1024), (2048 * 77 + 2047, 2, 2048), (5, 16, 2048), ((1 << 22) + 3, 16, 256),
+                         (100003, 16, 100)]:
         x = rng.randn(n).astype(np.float32)
-        h = codec.level_histogram(dev(x), s, bucket)
-        assert np.array_equal(host(h), np.bincount(oc.uniform_quantize(x, s, bucket)['lev'], minlength=s)), (n, s, bucket)
+        want = np.bincount(oc.uniform_quantize(x, s, bucket)['lev'], minlength=s)
+        h = codec.level_histogram(dev(x), s, bucket)        # one pass at the vector bucket sizes (qd_level_histogram_f32), levels + count elsewhere
+        assert h.dtype == torch.int64 and np.array_equal(host(h), want), (n, s, bucket)
+        if n > 8:
+            assert np.array_equal(host(codec.level_histogram(dev(x)[1:], s, bucket)),
+                                  np.bincount(oc.uniform_quantize(x[1:], s, bucket)['lev'], minlength=s)), (n, s, bucket, 'view at +4 B')
+    # a bucket that holds a NaN: both forms count its elements as level 0 (what the uint8 level output stores for them)
+    x = rng.randn(256 * 50).astype(np.float32)
+    x[256 * 7 + 3] = np.nan
+    h_fused, h_two = host(codec.level_histogram(dev(x), 16, 256)), host(codec.level_histogram(dev(np.concatenate([[0.0], x]).astype(np.float32))[1:], 16, 256))
+    assert np.array_equal(h_fused, h_two) and h_fused.sum() == x.size
     idx = rng.randint(0, 200, size=1 << 21).astype(np.uint8)
     assert np.array_equal(host(codec.histogram_u8(dev(idx), 256)), np.bincount(idx, minlength=256))
     assert np.array_equal(host(codec.histogram_u8(dev(idx[3:]), 256)), np.bincount(idx[3:], minlength=256))   # unaligned

@@ -104,7 +104,7 @@ def calls():
     lev = torch.randint(0, 16, (N,), dtype=torch.uint8, device=dev)
     for k in (16, 256):
         case('codec.histogram_u8 k=%d' % k, lambda: codec.histogram_u8(lev, k))
-    case('codec.level_histogram s=16 bucket=256 (levels only)', lambda: codec.level_histogram(x, 16, 256))
+    case('codec.level_histogram s=16 bucket=256 (one pass)', lambda: codec.level_histogram(x, 16, 256))
     case('codec.level_histogram s=16 bucket=100 (q-writing form)', lambda: codec.level_histogram(x, 16, 100))
     case('get_huffman_encoding_mean_bit_length uniform s=16 bucket=256',
          lambda: qhf.get_huffman_encoding_mean_bit_length(iter([x]), lambda t: quantization.uniformQuantization(t, 16, bucket_size=256), 'uniform', s=16))

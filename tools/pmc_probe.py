@@ -68,7 +68,7 @@ pk = codec.pack_uniform(xs[0], 16, 256)
 counts['k_pack_vec<16, 4, 4>'] += 1
 record('UPK unpack 4-bit', 'k_unpack<4>', int(4.5 * N), lambda i: keep.append(pk.unpack()))
 lev8 = [torch.randint(0, 16, (N,), dtype=torch.uint8, device=dev) for _ in range(3)]
-record('LV8 levels only (qd_uniform_f32 with q == NULL)', 'k_pack_vec<16, 4, 8>', 5 * N,
+record('LVH level histogram of x in one pass', 'k_level_hist_vec<16, 4>', 4 * N,
        lambda i: keep.append(codec.level_histogram(xs[i], 16, 256)))
 sfh = quantization.ScalingFunction('linear', False, False, 256)
 uu = sfh.scale_down(xs[1]).view(-1)
