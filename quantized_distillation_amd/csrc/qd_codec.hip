@@ -467,14 +467,30 @@ __global__ __launch_bounds__(256) void k_level_hist_vec(const float* x, int64_t 
         if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); } else { mn = wave_min(mn); mx = wave_max(mx); }
         float a, b;
         alpha_beta(mn, mx, a, b);
+        // only the LEVEL of u is consumed: the bucket-invariant division (qd_common.h) is exact here, taken when every bucket
+        // of the wave is in its proven range (wave-uniform choice, as in the quantize kernels)
+        const bool fast = !__any(!fastdiv_ok(a));
+        const float ry = 1.0f / a;
+        if (fast) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float lev[4];
-            qdq(v[j].x, a, b, sm1, 0.0f, lev[0]);
-            qdq(v[j].y, a, b, sm1, 0.0f, lev[1]);
-            qdq(v[j].z, a, b, sm1, 0.0f, lev[2]);
-            qdq(v[j].w, a, b, sm1, 0.0f, lev[3]);
-            bump(lev[0]); bump(lev[1]); bump(lev[2]); bump(lev[3]);
+            for (int j = 0; j < V; ++j) {
+                float lev[4];
+                qdq<true>(v[j].x, a, b, sm1, 0.0f, lev[0], ry);
+                qdq<true>(v[j].y, a, b, sm1, 0.0f, lev[1], ry);
+                qdq<true>(v[j].z, a, b, sm1, 0.0f, lev[2], ry);
+                qdq<true>(v[j].w, a, b, sm1, 0.0f, lev[3], ry);
+                bump(lev[0]); bump(lev[1]); bump(lev[2]); bump(lev[3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float lev[4];
+                qdq(v[j].x, a, b, sm1, 0.0f, lev[0]);
+                qdq(v[j].y, a, b, sm1, 0.0f, lev[1]);
+                qdq(v[j].z, a, b, sm1, 0.0f, lev[2]);
+                qdq(v[j].w, a, b, sm1, 0.0f, lev[3]);
+                bump(lev[0]); bump(lev[1]); bump(lev[2]); bump(lev[3]);
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 64 && nvec * ROW < n) {           // the short last bucket [nvec * ROW, n)
@@ -695,7 +711,7 @@ int qd_level_histogram_f32(const float* x, int64_t n, int64_t bucket, int levels
 #define QD_LH(LPB, V)                                                                                                 \
     {                                                                                                                 \
         const int64_t tiles = (nfull + (64 / LPB) - 1) / (64 / LPB);                                                  \
-        int blocks = blocks_for(tiles > 0 ? tiles : 1, 4, device_cus() * 4);                                          \
+        int blocks = blocks_for(tiles > 0 ? tiles : 1, 4, device_cus() * 8);                                          \
         const size_t room = workspace_bytes / ((size_t)levels * sizeof(unsigned long long));                          \
         if ((size_t)blocks > room) blocks = (int)room;                                                                \
         if (blocks < 1) return QD_ERR_WORKSPACE_TOO_SMALL;                                                            \
