@@ -425,8 +425,8 @@ __device__ __forceinline__ void store_side4_row(const KParams& p, int64_t e, con
         const uint32_t ca = odd ? a_hi : a_lo, cb = odd ? b_hi : b_lo;
         const l2 va = {(int64_t)(ca & 0xFFFFu), (int64_t)(ca >> 16)}, vb = {(int64_t)(cb & 0xFFFFu), (int64_t)(cb >> 16)};
         l2* o = (l2*)((int64_t*)p.idx + (e - (int64_t)l16 * 4));          // the row's first element
-        o[l16] = va;                  // plain stores: 175.8 us vs 180.0 us with the non-temporal hint (k = 4)
-        o[16 + l16] = vb;
+        o[l16] = va;                  // plain stores: 175.8 us vs 180.0 us with the non-temporal hint (k = 4, round 3); round 4, index output
+        o[16 + l16] = vb;             // kept alive by the caller: 201.0 vs 199.4 us, no difference either way (profiles/r04_ab_idx_stores.txt)
     } else {
         store_side4<MODE>(p, e, s);
     }
