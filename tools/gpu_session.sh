@@ -46,7 +46,7 @@ for step in "$@"; do
     prof)    rm -rf gpurun_out/prof_stats gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
              (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o bench -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-distill --no-pmc > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "stats rc=$?"
              for c in FETCH_SIZE WRITE_SIZE; do
-               (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o bench -- python $R/bench.py --steps 10 --warmup 2 --precondition-s 0.05 --no-cpu-baseline --no-distill --no-pmc > /dev/null 2> $R/gpurun_out/pmc_$c.err); echo "pmc $c rc=$?"
+               (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o bench -- python $R/bench.py --steps 10 --warmup 2 --precondition-s 0.05 --no-cpu-baseline --no-distill --no-pmc --no-kernels > /dev/null 2> $R/gpurun_out/pmc_$c.err); echo "pmc $c rc=$?"
              done ;;
     pmck)    rm -rf gpurun_out/pmcK_FETCH_SIZE gpurun_out/pmcK_WRITE_SIZE
              for c in FETCH_SIZE WRITE_SIZE; do
