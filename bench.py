@@ -244,7 +244,7 @@ def distill_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=100
         modes = modes + ('multi_graph',)
 
     # The 2 ms step is ~150 small launches (MIOpen's small-shape convolutions, batch-norm, the optimizer) and its time
-    # moves from repetition to repetition on one box (profiles/r03_distill_spread.txt).  So: REPS repetitions of `steps`
+    # moves from repetition to repetition on one box (docs/history/profiles/r03_distill_spread.txt).  So: REPS repetitions of `steps`
     # steps per mode, INTERLEAVED (multi, per_tensor, multi, ...) so that drift hits both alike; the MEDIAN is reported,
     # every repetition is listed, and the two modes are only called different when their ranges do not overlap.
     REPS = repetitions

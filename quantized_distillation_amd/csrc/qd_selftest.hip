@@ -5,7 +5,7 @@
 // qd_selftest_div_invariant() generates adversarial (n, alpha) pairs ON THE DEVICE, evaluates the shortcut exactly as the
 // kernels do -- y = RN(1 / alpha) by a true division, then q = RN(n y), r = fma(-alpha, q, n), u = fma(r, y, q); this file
 // is compiled with the library's flags and calls the same inline function -- and compares the bits with the IEEE quotient
-// n / alpha.  tools/div_invariant_check.py drives it over >= 10^9 pairs per family (profiles/r03_div_invariant.txt);
+// n / alpha.  tools/div_invariant_check.py drives it over >= 10^9 pairs per family (docs/history/profiles/r03_div_invariant.txt);
 // tests/test_hip_parity.py::test_division_by_bucket_invariant_alpha runs a 10^8-pair slice on every GPU test run.
 //
 // Domain of the claim (qd_common.h): alpha in [2^-60, 2^100] (fastdiv_ok), n = 0 or 2^-100 <= n, n / alpha finite.  In

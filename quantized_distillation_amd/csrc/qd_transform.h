@@ -103,7 +103,7 @@ constexpr int kSmallTable = 32;
 // 64 lanes does: about once per three float4 instead of for every element).  Why: at k = 256 the kernel is bound by VALU
 // issue and LDS bank conflicts, not by latency -- 61 M VALU wave-instructions per 64 Mi-element launch (25 M at k = 4), half
 // of its 35.7 M LDS-active cycles lost to conflicts of five to six random table reads per element
-// (profiles/r03_sq_counters.txt).  Points crowded into few cells (percentile-initialised, bell-shaped weights) keep taking the
+// (docs/history/profiles/r03_sq_counters.txt).  Points crowded into few cells (percentile-initialised, bell-shaped weights) keep taking the
 // fallback: never slower than the narrowed search it replaces, only no faster.  16 KB more LDS, so only the kernels without
 // LDS staging of their own use it (`fine` is cleared for the chunk kernels), on a capped grid (kFineBlocksPerCu) so that
 // the table is built a few thousand times, not once per 16 KB of data.
@@ -128,7 +128,7 @@ __host__ __device__ constexpr size_t point_table_bytes(int k, int fine = 0) {
 // pre-processed forward got slower at every bucket size -- k = 4, bucket 256 / 100 / 1000: 107 / 192 / 130 us against
 // 93 / 114 / 97 us with the joint LDS search of count_before4.  With k <= 4 in vector registers (+26 VGPRs in the chunk
 // kernel) it tied or lost on the per-step call (bucket 100: 119 us against 105 us) and gained 5-10 % on the one-off
-// nonUniformQuantization call only.  profiles/r03_side_outputs.txt.)
+// nonUniformQuantization call only.  docs/history/profiles/r03_side_outputs.txt.)
 struct PointTable {
     const PointStore* s;
     bool fine;
@@ -311,7 +311,7 @@ __device__ __forceinline__ float transform(const KParams& p, const PointTable* T
 // and LDS bank conflicts, not by latency (at k = 256: 64 M VALU wave-instructions per 64 Mi-element launch ~ 105 us of
 // issue time, half of the 35.7 M LDS-active cycles lost to conflicts of random reads in 256-entry tables), and both a
 // joint narrowed search with always-issued reads (134 us against 115 us) and merely routing the four per-element searches
-// through this function (125 us) measured slower.  profiles/r03_sq_counters.txt.
+// through this function (125 us) measured slower.  docs/history/profiles/r03_sq_counters.txt.
 __device__ __forceinline__ void assign_point4(const PointStore& T, int k, int mode, const float (&u)[4], int (&i)[4]) {
     if (mode == QD_ASSIGN_MIDPOINT) {
         count_before4<true>(T.mid, k - 1, u, i);
@@ -919,7 +919,7 @@ void k_bucket_chunk_any(KParams p, int m, int64_t nchunks, int lead) {
     // Side outputs (level / point indices up to 255) are staged as ONE BYTE per element behind the values -- a quarter more
     // LDS, only when such an output is asked for -- and leave with the values: four per lane, coalesced.  Stored from the
     // transform loop they would leave element by element in LDS order (lanes a bucket apart): 216 us instead of 95 us for
-    // quantize + levels at bucket 33, 405 us for int64 point indices (profiles/r03_side_outputs.txt).  (Up to 32 points: with
+    // quantize + levels at bucket 33, 405 us for int64 point indices (docs/history/profiles/r03_side_outputs.txt).  (Up to 32 points: with
     // the 10.3 KB table of a larger point set the extra bytes cost a resident block, which measured slower than the scattered
     // stores: k = 256 at bucket 33: 316 us against 281 us.)
     const bool stage8 = (MODE == MODE_QDQ && p.lev8 != nullptr) || (MODE == MODE_NEAREST && p.idx != nullptr && p.k <= 32);

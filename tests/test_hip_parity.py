@@ -1347,7 +1347,7 @@ def test_division_by_bucket_invariant_alpha():
     wide exponents, all-ones / near-power-of-two significands, near-exact quotients around level values, the edges of the
     stated ranges, small normal quotients down to 2^-120 -- what scale_down adds) through the very inline function the kernels use (qd_selftest_div_invariant, csrc/qd_selftest.hip)
     against the IEEE quotient: 0 mismatches required.  tools/div_invariant_check.py --pairs 1e9 is the long run
-    (profiles/r03_div_invariant.txt).  ref: quant_functions.py:106-107."""
+    (docs/history/profiles/r03_div_invariant.txt).  ref: quant_functions.py:106-107."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import div_invariant_check as dic

@@ -209,8 +209,9 @@ def test_committed_bench_lines_keep_the_contract_and_are_self_consistent():
     import glob
     import json
     import os
+    from harness.dpbench import DP_KEYS
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r03_bench*.json')))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r04_bench*.json')))
     assert len(files) >= 3
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
@@ -229,7 +230,27 @@ def test_committed_bench_lines_keep_the_contract_and_are_self_consistent():
         assert abs(r['frac'] - r['achieved'] / r['peak']) <= 1e-3
         whole = d['n_gpus'] * algo / (d['ms_per_step'] * 1e-3) / 1e9
         assert abs(d['value'] - whole) <= 2e-3 * whole, (f, d['value'], whole)
-        assert d['value'] <= r['achieved'] * 1.001
+        assert d['value'] <= d['n_gpus'] * r['achieved'] * 1.001
+        # the per-kernel rows (every default / driver-flag run at N = 1 carries them): self-consistent, and mirrored as scalars
+        rows = r.get('kernels')
+        if rows is not None:
+            assert isinstance(rows, list) and len(rows) >= 14, (f, rows if not isinstance(rows, list) else len(rows))
+            for i, row in enumerate(rows):
+                for key in ('name', 'kernel', 'us', 'bytes_per_elem', 'GBps', 'frac'):
+                    assert key in row, (f, i, key)
+                assert abs(row['GBps'] - row['bytes_per_elem'] * row['n'] / row['us'] / 1e3) <= 2e-3 * row['GBps'] + 0.2, (f, row)
+                assert abs(row['frac'] - row['GBps'] / 8000.0) <= 1e-3, (f, row)
+                flat = r['k%02d' % (i + 1)]
+                assert isinstance(flat, str) and len(flat) <= 118 and flat.startswith(row['name'][:20]), (f, flat)
+            headline = rows[0]
+            assert abs(headline['us'] - r['avg_launch_us']) <= 0.05 * r['avg_launch_us'], (f, headline['us'], r['avg_launch_us'])
+        # the steps/sec legs carry the data-parallel report
+        for leg in ('diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp'):
+            rec = (d.get('distill') or {}).get(leg)
+            if isinstance(rec, dict) and 'steps_per_sec' in rec:
+                for key in DP_KEYS:
+                    assert key in rec or (key in ('allreduce_alone_ms', 'busbw_GBps', 'algbw_GBps', 'xgmi_peak_GBps_per_gpu') and rec['exchanged_bytes_per_step'] == 0), (f, leg, key)
+                assert rec['n_gpus'] == d['n_gpus']
         if r['traffic'] is not None:
             assert 0.98 * algo <= r['traffic'] <= 1.02 * algo, (f, r['traffic'])
         if 'cpu_baseline' in d and d['cpu_baseline']:

@@ -10,7 +10,7 @@ division by a loop invariant).  This tool checks that claim two ways:
   device (needs a GPU):  python tools/div_invariant_check.py --pairs 1e9
       runs qd_selftest_div_invariant (csrc/qd_selftest.hip: the very inline function the kernels use, compiled with the
       library's flags) over `--pairs` adversarial pairs per family and prints tested / mismatches per family;
-      exit status 1 on any mismatch.  Output of the committed run: profiles/r03_div_invariant.txt.
+      exit status 1 on any mismatch.  Output of the committed run: docs/history/profiles/r03_div_invariant.txt.
 
   host (no GPU):         python tools/div_invariant_check.py --cpu 200000
       restates the three operations in EXACT rational arithmetic (fractions.Fraction, one explicit round-to-nearest-even
