@@ -540,6 +540,8 @@ def main():
             dist.init_process_group('nccl', device_id=dev, timeout=legs.data_timeout())    # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend, timeout=legs.data_timeout())
+        if world == 1:
+            os.environ['QD_FORCE_DIST'] = '1'    # one rank under the launcher: the collectives are still issued (as in the branch below)
     else:
         # single process: still a (one-rank) RCCL group, and QD_FORCE_DIST=1 makes the harness issue its
         # collectives in it, so that the all-reduce path of the steps/sec legs is executed and timed on this box
