@@ -258,3 +258,20 @@ def test_committed_bench_lines_keep_the_contract_and_are_self_consistent():
             for key in ('value', 'unit', 'cores', 'kind', 'sample'):
                 assert key in c, (f, key)
             assert c['kind'] in ('reference', 'port') and c['value'] < d['value'] / 100
+
+
+def test_kernel_bench_helpers_without_a_gpu():
+    """harness/kernel_bench.py: the shape lists it times the multi-tensor kernels on are the parameter shapes of the BASELINE
+    config models, and a row's one-line form fits what the driver's record keeps of a string."""
+    from harness import kernel_bench, models
+    wrn = kernel_bench.model_shapes('wrn')
+    assert len(wrn) == 60 and sum(int(np.prod(s)) for s in wrn) == 82746890
+    st = kernel_bench.model_shapes('student')
+    assert len(st) == 22 and sum(int(np.prod(s)) for s in st) == 1000235
+    assert st == [tuple(p.shape) for p in models.student().parameters()]
+    row = {'name': 'K5 diff-quant forward k=16 (u resident, u8 idx)', 'kernel': 'k_nearest_prescaled_stream<false>', 'us': 91.73,
+           'bytes_per_elem': 9, 'GBps': 6584.6, 'frac': 0.8231, 'n': 1 << 26}
+    flat = kernel_bench.flat_row(row)
+    assert len(flat) <= 118 and flat.startswith('K5 diff-quant forward k=16') and '| 91.73 us | 9 B/el | 6585 GB/s | 0.823 |' in flat
+    with pytest.raises(ValueError):
+        kernel_bench.model_shapes('nope')
