@@ -189,3 +189,24 @@ def test_uniform_subtract_mean_matches_oracle(n, bucket, s, seed, kind, clamp):
     assert np.array_equal(q.cpu().numpy(), r['q'])
     assert np.array_equal(sf.alpha.cpu().numpy().reshape(-1), r['alpha'])
     assert np.array_equal(sf.beta.cpu().numpy().reshape(-1), r['beta'])
+
+
+@settings(max_examples=40 * SOAK, deadline=None, suppress_health_check=list(HealthCheck))
+@given(n=sizes, bucket=buckets, s=st.sampled_from([2, 4, 16, 16, 255, 256]), seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 8),
+       off=st.sampled_from([0, 0, 1, 3]))
+def test_level_and_digitize_histograms_match_numpy(n, bucket, s, seed, kind, off):
+    """The counting kernels of the size accounting (round 4): the level histogram of a tensor (one pass at the vector bucket
+    sizes, levels + count elsewhere) against the C oracle's levels, and the digitize + histogram of the re-scaled quantized
+    tensor against np.digitize with the reference's float64 edges (quantization/help_functions.py:213-223)."""
+    import quantization.help_functions as qhf
+    from quantized_distillation_amd import codec
+    x = make(n + off, seed, kind)[off:]
+    xd = torch.from_numpy(make(n + off, seed, kind)).to(DEV)[off:]
+    h = codec.level_histogram(xd, s, bucket)
+    assert np.array_equal(h.cpu().numpy(), np.bincount(oc.uniform_quantize(x, s, bucket)['lev'], minlength=s))
+    q, sf = quantization.uniformQuantization(xd, s, bucket_size=bucket)
+    scaled = sf.scale_down(q).view(-1)[0:sf.original_tensor_length]
+    edges = qhf._digitize_edges(s, 1e-5)
+    got = qhf._device_counts('digitize', scaled, s, torch.from_numpy(edges).to(DEV))
+    want = np.bincount(np.digitize(scaled.cpu().numpy(), edges), minlength=s + 1)
+    assert np.array_equal(got.cpu().numpy(), want)
