@@ -158,7 +158,7 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         pts = torch.sort(torch.rand(k, device=dev, generator=gen))[0]
         add('K4 nonUniform k=%d b256 (int64 idx)' % k, 'k_bucket_vec<2,16,4,1>',
             lambda i, pts=pts: keep(i, quantization.nonUniformQuantization(xs[i % R], pts, bucket_size=256)[:2]), 16, N,
-            note='q AND the int64 indices of the last 4 calls stay alive: every call writes 768 MB of fresh memory')
+            note='q and the int64 indices of the last 4 calls stay alive; 177-201 us box to box with one binary (profiles/r04_ab_idx_stores.txt)')
         fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=xs[j]) for j in range(3)]
         add('K5 diff-quant forward k=%d (u resident, u8 idx)' % k, 'k_nearest_prescaled_stream<false>',
             lambda i, pts=pts, fns=fns: fns[i % 3].forward(None, pts), 9, N)
