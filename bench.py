@@ -415,16 +415,56 @@ def load_pmc_traffic():
         return None
 
 
-def pmc_slice():
-    """Child of measure_pmc_traffic(): a dozen launches of the headline call under rocprofv3, nothing else."""
+def pmc_slice(launches=12):
+    """Child of measure_pmc_traffic() / measure_rocprof_duration(): `launches` launches of the headline call under rocprofv3,
+    nothing else."""
     import quantization
     dev = torch.device('cuda', 0)
     gen = torch.Generator().manual_seed(0)
-    xs = [torch.randn(N_ELEM, generator=gen).to(dev) for _ in range(2)]
-    live = [None, None]
-    for i in range(12):
-        live[i % 2] = quantization.uniformQuantization(xs[i % 2], LEVELS, bucket_size=BUCKET)[0]
+    nbuf = 2 if launches <= 12 else N_ROTATE
+    xs = [torch.randn(N_ELEM, generator=gen).to(dev) for _ in range(nbuf)]
+    live = [None] * nbuf
+    for i in range(launches):
+        live[i % nbuf] = quantization.uniformQuantization(xs[i % nbuf], LEVELS, bucket_size=BUCKET)[0]
     torch.cuda.synchronize()
+
+
+def measure_rocprof_duration(launches=1200, timeout_s=150):
+    """The headline kernel's average duration as rocprofv3 sees it, IN THIS RUN: `rocprofv3 --kernel-trace --stats` over a child
+    process that does `launches` back-to-back launches of the same call (the first third is dropped: clocks and allocator
+    settle).  What roofline.avg_launch_us (HIP events around the timed region, gaps included) has to agree with."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return {'error': 'rocprofv3 not found'}
+    with tempfile.TemporaryDirectory(dir='/tmp') as td:
+        env = dict(os.environ, TMPDIR='/tmp')
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'QD_FORCE_DIST'):
+            env.pop(k, None)
+        cmd = [exe, '--kernel-trace', '--output-format', 'csv', '-d', td, '-o', 'dur', '--',
+               sys.executable, os.path.abspath(__file__), '--pmc-slice', '--pmc-slice-launches', str(launches)]
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return {'error': 'rocprofv3 --kernel-trace timed out after %d s' % timeout_s}
+        files = glob.glob(os.path.join(td, '**', '*kernel_trace.csv'), recursive=True)
+        if r.returncode != 0 or not files:
+            return {'error': 'rocprofv3 --kernel-trace: rc %d, %d trace files; %s' % (r.returncode, len(files), r.stderr.decode(errors='replace')[-300:])}
+        d = []
+        with open(files[0]) as fh:
+            for row in csv.DictReader(fh):
+                if 'k_bucket_vec' in row.get('Kernel_Name', ''):
+                    d.append((int(row['Start_Timestamp']), (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3))
+    d = [us for _t, us in sorted(d)][len(d) // 3:]
+    if not d:
+        return {'error': 'no k_bucket_vec dispatch in the trace'}
+    return {'avg_us': round(sum(d) / len(d), 3), 'min_us': round(min(d), 3), 'max_us': round(max(d), 3), 'launches': len(d),
+            'how': 'rocprofv3 --kernel-trace over %d launches of the headline call in a child process of this run; per-dispatch '
+                   'End - Start of k_bucket_vec, the first third dropped' % launches}
 
 
 def measure_pmc_traffic(timeout_s=150):
@@ -494,9 +534,10 @@ def main():
     ap.add_argument('--skip-legs', default='', help='comma-separated steps/sec legs to leave out (cifar_student, diffquant_wrn, imagenet_resnet18k_dp, nmt_lstm_dp)')
     ap.add_argument('--quick', action='store_true', help='short steps/sec legs (a few steps, two repetitions): for exercising the flow, not for numbers')
     ap.add_argument('--pmc-slice', action='store_true', help=argparse.SUPPRESS)       # child mode of measure_pmc_traffic()
+    ap.add_argument('--pmc-slice-launches', type=int, default=12, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_slice:
-        pmc_slice()
+        pmc_slice(args.pmc_slice_launches)
         return
 
     from harness import launch, legs
@@ -719,6 +760,16 @@ def main():
             roofline['traffic'] = int(traffic_measured['bytes_per_launch'])
             roofline['traffic_source'] = 'measured in this run (traffic_measured)'
             roofline['traffic_over_algorithmic'] = traffic_measured['over_algorithmic']
+        # ... and the kernel's duration as rocprofv3 sees it, next to the HIP-event figure above
+        try:
+            dur = measure_rocprof_duration()
+        except Exception as e:                                    # noqa: BLE001
+            dur = {'error': '%s: %s' % (type(e).__name__, e)}
+        roofline['rocprof_kernel'] = dur
+        if dur.get('avg_us'):
+            roofline['rocprof_kernel_avg_us'] = dur['avg_us']
+            roofline['rocprof_kernel_launches'] = dur['launches']
+            roofline['rocprof_frac'] = round(bytes_per_launch / (dur['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
 
     # cpu_baseline leg (rank 0, N=1 only): the oracle is timed on the host cores and, in the same leg,
     # used as the checker of the GPU result computed above (bit-exact comparison)

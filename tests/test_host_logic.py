@@ -231,6 +231,10 @@ def test_committed_bench_lines_keep_the_contract_and_are_self_consistent():
         whole = d['n_gpus'] * algo / (d['ms_per_step'] * 1e-3) / 1e9
         assert abs(d['value'] - whole) <= 2e-3 * whole, (f, d['value'], whole)
         assert d['value'] <= d['n_gpus'] * r['achieved'] * 1.001
+        # the kernel's duration by rocprofv3 in the same run: what the HIP-event average (launch gaps included) has to agree with
+        if r.get('rocprof_kernel_avg_us'):
+            assert 0.95 * r['avg_launch_us'] <= r['rocprof_kernel_avg_us'] <= 1.01 * r['avg_launch_us'], (f, r['rocprof_kernel_avg_us'], r['avg_launch_us'])
+            assert r['rocprof_kernel_launches'] >= 500
         # the per-kernel rows (every default / driver-flag run at N = 1 carries them): self-consistent, and mirrored as scalars
         rows = r.get('kernels')
         if rows is not None:
