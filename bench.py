@@ -541,6 +541,7 @@ def main():
         return
 
     from harness import launch, legs
+    legs.rccl_env_defaults()                 # (before the first HIP call: the runtime reads HSA_ENABLE_IPC_MODE_LEGACY when it starts)
     if args.gpus > 1 and not launch.under_launcher():
         # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, RCCL over xGMI
         if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
@@ -575,7 +576,6 @@ def main():
     import torch.distributed as dist
     distributed = world > 1                  # the timed region's barriers: only where there is somebody to wait for
     rccl_error = None
-    legs.rccl_env_defaults()                 # a timed-out collective raises on the waiting ranks instead of ending them
     if launch.under_launcher():
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev, timeout=legs.data_timeout())    # "nccl" is RCCL on ROCm
@@ -611,6 +611,29 @@ def main():
             emit({'error': 'deadline of %.0f s reached: the line holds what had been measured by then' % args.deadline_s,
                   'legs_failed': runner.history})
     deadline = legs.Deadline(args.deadline_s, expired)
+
+    # Pre-flight: ONE small all-reduce through the data-path communicator before anything depends on it.  If RCCL cannot move
+    # bytes on this node (no IPC path between the GPUs, a dead link) every rank learns it here, inside the group's timeout:
+    # the headline then runs per GPU without the barriers of the timed region, the collective-bearing legs are skipped, and
+    # rank 0's line says so -- instead of N ranks hanging in their first barrier.
+    if distributed:
+        pre_err = None
+        try:
+            if os.environ.get('QD_BENCH_TEST_PREFLIGHT_FAIL') == str(rank):      # test hook (tests/test_hip_bench_ranks.py)
+                raise RuntimeError('pre-flight failure requested by the test')
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            if int(t[0]) != world:
+                pre_err = 'all-reduce of ones over %d ranks returned %r' % (world, float(t[0]))
+        except Exception as e:                                    # noqa: BLE001
+            pre_err = '%s: %s' % (type(e).__name__, e)
+        failed = runner.agree(pre_err is None)
+        if failed:
+            rccl_error = 'pre-flight all-reduce failed on rank(s) %s%s' % (failed, ': ' + pre_err if pre_err else '')
+            runner.broken = rccl_error
+            distributed = False              # no collective in the timed region: every rank measures its own GPU
+            line['error'] = rccl_error + '; value is rank 0 alone x n_gpus (NOT a max over ranks), the steps/sec legs were skipped'
 
     import quantization
     from quantized_distillation_amd import _lib

@@ -46,7 +46,10 @@ def rccl_env_defaults(env=None):
     return env
 
 
-def data_timeout(seconds=DATA_TIMEOUT_S):
+def data_timeout(seconds=None):
+    """Timeout of the data-path group's collectives (QD_BENCH_DATA_TIMEOUT_S overrides the default: the tests use a short one)."""
+    if seconds is None:
+        seconds = float(os.environ.get('QD_BENCH_DATA_TIMEOUT_S', DATA_TIMEOUT_S))
     return datetime.timedelta(seconds=seconds)
 
 

@@ -50,3 +50,23 @@ def test_two_ranks_quick_run_end_to_end():
     assert isinstance(r['steps_cfg1'], str) and 'multi' in r['steps_cfg1']
     for key in ('dp_cfg1', 'dp_cfg3_imagenet'):
         assert isinstance(r[key], str) and len(r[key]) <= 118 and 'N=2' in r[key], (key, r.get(key))
+
+
+def test_a_failed_preflight_collective_still_yields_the_line():
+    """If the data-path communicator cannot move bytes (here: rank 1 is told to fail its pre-flight all-reduce) the run must
+    not hang in its first barrier: the headline is measured per GPU, every collective-bearing leg is skipped and recorded as
+    such, rank 0 prints the line with the error, every rank exits 0."""
+    env = dict(os.environ, QD_BENCH_BACKEND='gloo', QD_BENCH_ONE_GPU='1', QD_BENCH_TEST_PREFLIGHT_FAIL='1', QD_BENCH_DATA_TIMEOUT_S='8')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = launch.launcher_command(os.path.join(ROOT, 'bench.py'), 2, ['--gpus', '2', '--steps', '5', '--warmup', '2', '--quick', '--no-cpu-baseline',
+                                                                       '--no-pmc', '--no-kernels', '--precondition-s', '0.05'])
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert 'pre-flight' in d['error'] and 'pre-flight' in d['rccl_error'] and '1]' in d['rccl_error']     # rank 1, and rank 0 that waited for it in vain
+    assert d['n_gpus'] == 2 and d['value'] > 0
+    for name, leg in d['distill'].items():
+        assert 'skipped' in leg and 'pre-flight' in leg['skipped'], (name, leg)
