@@ -427,6 +427,28 @@ def pmc_slice(launches=12):
     for i in range(launches):
         live[i % nbuf] = quantization.uniformQuantization(xs[i % nbuf], LEVELS, bucket_size=BUCKET)[0]
     torch.cuda.synchronize()
+    if launches <= 12:
+        # the PMC passes also see a few launches of the other per-step kernels (OTHER_PMC_KERNELS): 6 each, N = 64 Mi
+        sf = quantization.ScalingFunction('linear', False, False, BUCKET)
+        for i in range(6):
+            live[i % nbuf] = sf.scale_down(xs[i % nbuf])                                               # K2
+        pts = torch.tensor([0.0, 0.3, 0.7, 1.0], device=dev)
+        fns = [quantization.nonUniformQuantization_variable(bucket_size=BUCKET, pre_process_tensors=True, tensor=x) for x in xs]
+        g = torch.randn(N_ELEM, generator=gen).to(dev)
+        for i in range(6):
+            fns[i % nbuf].forward(None, pts)                                                           # K5
+        for i in range(6):
+            fns[i % nbuf].backward(g)                                                                  # K6
+        torch.cuda.synchronize()
+
+
+# kernel-name substring -> (label, algorithmic bytes per launch) of what pmc_slice() launches beside the headline kernel;
+# the K2 entry also matches the two scale_down launches nonUniformQuantization_variable's constructor makes (same bytes)
+OTHER_PMC_KERNELS = {
+    'k_bucket_vec<1, 16, 4, 1>': ('K2 scale_down', 8 * N_ELEM),
+    'k_nearest_prescaled_stream<false>': ('K5 diff-quant forward', 9 * N_ELEM),
+    'k_point_grad_fast<4, 1, 1': ('K6 point gradient', 5 * N_ELEM),
+}
 
 
 def measure_rocprof_duration(launches=1200, timeout_s=150):
@@ -481,7 +503,7 @@ def measure_pmc_traffic(timeout_s=150):
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return {'error': 'rocprofv3 not found'}
-    raw = {}
+    raw, other_raw = {}, {}
     t_start = time.time()
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         with tempfile.TemporaryDirectory(dir='/tmp') as td:
@@ -498,20 +520,37 @@ def measure_pmc_traffic(timeout_s=150):
             if r.returncode != 0 or not files:
                 return {'error': 'rocprofv3 --pmc %s: rc %d, %d counter files; %s'
                                  % (counter, r.returncode, len(files), r.stderr.decode(errors='replace')[-300:])}
-            vals = {}
+            vals, others = {}, {k: {} for k in OTHER_PMC_KERNELS}
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
-                    if 'k_bucket_vec' in row.get('Kernel_Name', '') and row.get('Counter_Name') == counter:
+                    name = row.get('Kernel_Name', '')
+                    if row.get('Counter_Name') != counter:
+                        continue
+                    if 'k_bucket_vec<0, 16, 4, 1>' in name:
                         vals[int(row['Dispatch_Id'])] = vals.get(int(row['Dispatch_Id']), 0.0) + float(row['Counter_Value'])
+                    for sub in OTHER_PMC_KERNELS:
+                        if sub in name:
+                            d_ = others[sub]
+                            d_[int(row['Dispatch_Id'])] = d_.get(int(row['Dispatch_Id']), 0.0) + float(row['Counter_Value'])
             v = [vals[k] for k in sorted(vals)][2:]                       # drop the first two launches
             if not v:
                 return {'error': 'no k_bucket_vec dispatch in the %s pass' % counter}
             raw[counter] = {'per_launch_KiB_avg': sum(v) / len(v), 'launches': len(v), 'min': min(v), 'max': max(v)}
+            for sub, d_ in others.items():
+                w = [d_[k] for k in sorted(d_)][1:]
+                if w:
+                    other_raw.setdefault(sub, {})[counter] = sum(w) / len(w)
     read_b = 2.0 * raw['FETCH_SIZE']['per_launch_KiB_avg'] * 1024
     write_b = raw['WRITE_SIZE']['per_launch_KiB_avg'] * 1024
     algo = ALGO_BYTES_PER_ELEM * N_ELEM
+    other = {}
+    for sub, (label, abytes) in OTHER_PMC_KERNELS.items():
+        c = other_raw.get(sub, {})
+        if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+            hb = 2.0 * c['FETCH_SIZE'] * 1024 + c['WRITE_SIZE'] * 1024
+            other[label] = {'bytes_per_launch': round(hb), 'over_algorithmic': round(hb / abytes, 4), 'algorithmic_bytes_per_launch': abytes}
     return {'bytes_per_launch': round(read_b + write_b), 'read_bytes_per_launch': round(read_b), 'write_bytes_per_launch': round(write_b),
-            'over_algorithmic': round((read_b + write_b) / algo, 4), 'raw_KiB': raw, 'seconds': round(time.time() - t_start, 1),
+            'over_algorithmic': round((read_b + write_b) / algo, 4), 'raw_KiB': raw, 'other_kernels': other, 'seconds': round(time.time() - t_start, 1),
             'how': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace over 12 launches of the headline call in '
                    'a child process of this run; read = 2 x FETCH_SIZE x 1024 (gfx950 halves wide streaming reads), '
                    'write = WRITE_SIZE x 1024'}
@@ -783,6 +822,8 @@ def main():
             roofline['traffic'] = int(traffic_measured['bytes_per_launch'])
             roofline['traffic_source'] = 'measured in this run (traffic_measured)'
             roofline['traffic_over_algorithmic'] = traffic_measured['over_algorithmic']
+            for label, rec in (traffic_measured.get('other_kernels') or {}).items():        # scalars: what the driver's record keeps
+                roofline['traffic_over_algorithmic ' + label] = rec['over_algorithmic']
         # ... and the kernel's duration as rocprofv3 sees it, next to the HIP-event figure above
         try:
             dur = measure_rocprof_duration()

@@ -53,7 +53,7 @@ fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process
 # (preprocess ran K2 three more times)
 counts['k_bucket_vec<1, 16, 4, 1>'] = counts.get('k_bucket_vec<1, 16, 4, 1>', 0) + 4   # + sf.scale_down(xs[0]) above
 record('K5 diff-quant forward k=4 u8 idx', 'k_nearest_prescaled_stream<false>', 9 * N, lambda i: keep.append(fns[i].forward(None, pts)))
-record('K6 point gradient k=4 u8 idx', 'k_point_grad_fast<4, 1, 1, 4, false>', 5 * N, lambda i: keep.append(fns[i].backward(gs[i])[1]))
+record('K6 point gradient k=4 u8 idx', 'k_point_grad_fast<4, 1, 1, 4, false, false>', 5 * N, lambda i: keep.append(fns[i].backward(gs[i])[1]))
 fq = quantization.uniformQuantization_variable(16, bucket_size=256)
 
 
