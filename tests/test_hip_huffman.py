@@ -277,3 +277,32 @@ def test_api_on_a_device_that_is_not_current():
         g1, _ = quantization.uniformQuantization(x1, 16)
     q1b, _ = quantization.uniformQuantization(x1, 16, bucket_size=256)        # current device 0, tensor on 1
     assert torch.equal(q0.cpu(), q1.cpu()) and torch.equal(g0.cpu(), g1.cpu()) and torch.equal(q1.cpu(), q1b.cpu())
+
+
+def test_boundary_function_property_vs_the_reference():
+    """Random models (1-4 tensors of random sizes and value kinds -- ties, constant buckets, heavy tails, denormals, mixed
+    scales), s in {2, 4, 16, 256}, bucket in {None, 256, 100, 33, 7}: get_huffman_encoding_mean_bit_length of this package
+    on the device equals the staged reference's on the host to 1e-12, whatever the values are."""
+    import importlib
+    import os
+
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    from test_hip_property import make
+    refq = ref_stage.load()
+    assert refq is not None
+    refqhf = importlib.import_module(refq.__name__ + '.help_functions')
+    soak = int(os.environ.get('QD_SOAK', '1'))
+
+    @settings(max_examples=25 * soak, deadline=None, suppress_health_check=list(HealthCheck), derandomize=(soak == 1), database=None)
+    @given(sizes=st.lists(st.integers(1, 30000), min_size=1, max_size=4), s=st.sampled_from([2, 4, 16, 256]),
+           bucket=st.sampled_from([None, 256, 256, 100, 33, 7]), seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 8))
+    def check(sizes, s, bucket, seed, kind):
+        params = [torch.from_numpy(make(n, seed + i, kind if i % 2 == 0 else 0)) for i, n in enumerate(sizes)]
+        with np.errstate(all='ignore'):
+            want = refqhf.get_huffman_encoding_mean_bit_length(iter(params), lambda t: refq.uniformQuantization(t, s, bucket_size=bucket), 'uniform', s=s)
+        got = qhf.get_huffman_encoding_mean_bit_length(iter([p.to(DEV) for p in params]),
+                                                       lambda t: quantization.uniformQuantization(t, s, bucket_size=bucket), 'uniform', s=s)
+        assert abs(got - want) < 1e-12, (sizes, s, bucket, seed, kind, got, want)
+    check()
