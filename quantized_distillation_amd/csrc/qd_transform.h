@@ -432,6 +432,10 @@ __device__ __forceinline__ void store_side4_row(const KParams& p, int64_t e, con
     }
 }
 
+// (Round 4 measured the whole-wave form of this exchange -- each store instruction one contiguous KiB instead of four 256-byte
+// pieces at a 512-byte stride -- on the stream kernel: 189.7 us both ways.  The layout of the index stores is not what holds
+// the int64 calls at 67-71 % of the HBM peak; torch's own fp32 -> int64 conversion, the same 1 : 2 read : write mix, is the
+// yardstick: profiles/r04_ab_idx_stores.txt.)
 // ---- LANES lanes (16 = one DPP row, 64 = a wave) process one arbitrary bucket [lo, hi): scalar
 // accesses, two passes (the second pass re-reads from L1/L2).  Used for the ragged last bucket,
 // short buckets, odd bucket sizes and the multi-tensor kernel's unaligned cases.
