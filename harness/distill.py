@@ -191,16 +191,20 @@ class DistillTrainer(object):
     # ------------------------------------------------------------------ hipGraph replay of the step
     _graph_fb = None
 
-    def capture(self, *batch, warmup=3):
+    def capture(self, *batch, warmup=3, error_mode='thread_local', settle_s=0.35, _before_capture=None):
         """Capture the launch-bound part of the step in hipGraphs (torch.cuda.CUDAGraph): graph A =
         multi-tensor quantize + student/teacher forward + KD loss + backward, graph B = gradient clipping + the SGD
         update.  The gradient all-reduce stays between the two replays (eager RCCL call), so the
         distributed step is  A.replay(); all_reduce; B.replay().  Only for mode='multi'."""
-        self.capture_shapes([batch], warmup=warmup)
+        self.capture_shapes([batch], warmup=warmup, error_mode=error_mode, settle_s=settle_s, _before_capture=_before_capture)
 
-    def capture_shapes(self, batches, warmup=3):
+    def capture_shapes(self, batches, warmup=3, error_mode='thread_local', settle_s=0.35, _before_capture=None):
         """capture() for batches of SEVERAL shapes (the token batches of the seq2seq loop differ in length): one graph A per
-        distinct shape, each with its own static input buffers, all sharing one memory pool and the one graph B."""
+        distinct shape, each with its own static input buffers, all sharing one memory pool and the one graph B.
+
+        Safe next to a live RCCL process group (see capture_into / quiesce_collectives below): the capture is thread-local, the
+        collectives issued so far have been waited for and retired, and a capture that fails restores the caller's stream and
+        leaves this an eager trainer."""
         assert self.mode == 'multi', 'graph capture needs the persistent-shadow (multi) mode'
         assert self.style == 'none' and self.every == 1 and self._since >= 1, \
             'graph capture covers the plain every-step STE loop only'
@@ -243,19 +247,28 @@ class DistillTrainer(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         del saved_master, saved_buffers, saved_momenta
-        self._graphs, pool = {}, None
+        quiesce_collectives(self.sync, settle_s)
+        if _before_capture is not None:                  # test hook (tests/capture_worker.py: collectives in flight on purpose)
+            _before_capture()
+        graphs, pool, cell = {}, None, {}
         for key, sb in shapes.items():
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=side):     # the warm-up stream: its BLAS handles / workspaces exist
+
+            def body_a(sb=sb):
                 self.quantize()
-                loss = self.forward_backward(*sb)
+                cell['loss'] = self.forward_backward(*sb)
+            capture_into(g, body_a, pool=pool, stream=side, error_mode=error_mode)    # the warm-up stream: its BLAS handles / workspaces exist
             pool = g.pool()
-            self._graphs[key] = (sb, g, loss)
+            graphs[key] = (sb, g, cell.pop('loss'))
         gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb, pool=pool, stream=side):
+
+        def body_b():
             self.clip()
             self.opt.step()
-        self._graph_fb, self._graph_opt = self._graphs, gb
+        capture_into(gb, body_b, pool=pool, stream=side, error_mode=error_mode)
+        # only a COMPLETE set of graphs switches the trainer to replay: a capture that raised leaves it an eager trainer
+        self._graphs = graphs
+        self._graph_fb, self._graph_opt = graphs, gb
 
     def _step_graph(self, *batch):
         entry = self._graphs.get(tuple(tuple(t.shape) for t in batch))
@@ -268,6 +281,44 @@ class DistillTrainer(object):
         self.sync.sync()
         self._graph_opt.replay()
         return loss
+
+
+def quiesce_collectives(sync=None, settle_s=0.35):
+    """Before a stream capture in a process that has a c10d process group: wait for every collective this trainer has in
+    flight, drain the device, and give the backend's watchdog thread a few of its 100 ms polling periods to retire the finished
+    work items.  The watchdog polls the completion EVENT of every work item it still lists (hipEventQuery); with nothing listed
+    it has nothing to query while the capture runs.  (Round 4's driver run: that query, from the watchdog thread, hit a
+    global-mode capture -> "operation not permitted when stream is capturing" -> std::terminate.)"""
+    import time
+    import torch.distributed as dist
+    if sync is not None:
+        for h in getattr(sync, '_handles', ()):
+            h.wait()
+        sync._handles = []
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized() and settle_s > 0:
+        time.sleep(settle_s)
+
+
+def capture_into(graph, body, pool=None, stream=None, error_mode='thread_local'):
+    """body() captured into `graph` (a torch.cuda.CUDAGraph).
+
+    error_mode='thread_local' (hipStreamCaptureModeThreadLocal): only THIS thread's calls are checked against the capture, so
+    another thread's event query -- the c10d watchdog's -- neither fails nor invalidates it.  torch's default is 'global'.
+
+    torch.cuda.graph.__exit__ calls capture_end() BEFORE it leaves its stream context; when capture_end() raises, the capture
+    stream stays the current stream and everything launched afterwards lands on an invalidated stream ("operation failed due
+    to a previous error during capture").  So: whatever happens, the stream that was current before is current again."""
+    prev = torch.cuda.current_stream()
+    try:
+        with torch.cuda.graph(graph, pool=pool, stream=stream, capture_error_mode=error_mode):
+            body()
+    except BaseException:
+        torch.cuda.set_stream(prev)
+        raise
+    if torch.cuda.current_stream() != prev:              # (not expected: the context restores it on a clean exit)
+        torch.cuda.set_stream(prev)
 
 
 class TeacherAhead(object):

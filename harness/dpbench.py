@@ -73,7 +73,8 @@ def dp_report(step, steps, reps, dev, n_gpus, distributed, per_gpu_batch, grad_b
       exposed_comm_ms     step time minus the time of the same step with the exchange switched off,
       dp_efficiency       time of the step on ONE GPU (rank 0 alone, the others idle, no exchange) / data-parallel step time.
     set_exchange(bool) switches the step's exchange off and on; allreduce_once() issues the step's exchange once (None: the
-    step has none); ctl_barrier() must not touch the data-path communicator (harness/legs.py LegRunner.barrier)."""
+    step has none); ctl_barrier(ok) -> list of ranks that said not-ok, must not touch the data-path communicator
+    (harness/legs.py LegRunner.barrier)."""
     job, own = timed_steps(step, steps, reps, dev, distributed)
     ms = [t / steps * 1e3 for t in job]
     med = statistics.median(ms)
@@ -111,11 +112,20 @@ def dp_report(step, steps, reps, dev, n_gpus, distributed, per_gpu_batch, grad_b
         out['exposed_comm_ms'] = round(med - nocomm, 3)
         # ... and on ONE GPU with the others idle: the N = 1 time of this very leg, measured in this run
         if distributed:
-            n1 = None
+            n1, solo_err = None, None
             if rank == 0:
-                j1, _ = timed_steps(step, steps, reps, dev, False)
-                n1 = statistics.median(t / steps * 1e3 for t in j1)
-            ctl_barrier()                               # the other ranks wait here (gloo), off the GPUs
+                try:
+                    j1, _ = timed_steps(step, steps, reps, dev, False)
+                    n1 = statistics.median(t / steps * 1e3 for t in j1)
+                except Exception as e:                  # noqa: BLE001 -- told to the others below, then raised everywhere
+                    solo_err = e
+            # The other ranks wait here (gloo), off the GPUs.  The wait CARRIES rank 0's verdict: if its solo timing raised,
+            # every rank raises here, before the data-path broadcast below -- otherwise rank 0's end-of-leg agreement would
+            # pair with this in-leg one, the others would sit in the broadcast until the data timeout, and every later
+            # agreement would be off by one.
+            failed = ctl_barrier(solo_err is None) or []
+            if failed:
+                raise RuntimeError('the one-GPU-alone timing failed on rank(s) %s%s' % (failed, ': %s' % solo_err if solo_err else ''))
             t = torch.tensor([n1 if n1 is not None else 0.0], dtype=torch.float64, device=dev)
             dist.broadcast(t, src=0)
             n1 = float(t[0])

@@ -82,9 +82,26 @@ class LegRunner(object):
             return [r for r in range(self.world) if r != self.rank or not ok]
         return [r for r in range(self.world) if int(t[r])]
 
-    def barrier(self):
-        """A barrier that does not touch the data-path communicator."""
-        self.agree(True)
+    def rank0_says(self, flag):
+        """Rank 0's yes/no, known to every rank (over the control group): decisions that depend on a rank's own clock -- "does
+        this optional leg still fit the wall budget?" -- must come out the same everywhere, or one rank would skip a leg
+        whose collectives the others enter."""
+        if self.ctl is None:
+            return bool(flag)
+        t = torch.tensor([1 if (flag and self.rank == 0) else 0], dtype=torch.int32)
+        try:
+            dist.all_reduce(t, group=self.ctl)
+        except Exception as e:                                     # noqa: BLE001
+            self.log('legs: the control group failed (%s: %s)' % (type(e).__name__, e))
+            self.ctl = None
+            self.broken = self.broken or 'the control group failed: a rank died'
+            return False
+        return bool(int(t[0]))
+
+    def barrier(self, ok=True):
+        """A barrier that does not touch the data-path communicator; it carries one bit per rank (returns the ranks that
+        passed ok=False), so that an in-leg wait can tell the others "do not enter the next collective"."""
+        return self.agree(ok)
 
     # ------------------------------------------------------------------ one leg
     def run(self, name, fn, *args, collective=True, **kwargs):

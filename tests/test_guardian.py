@@ -1,0 +1,138 @@
+"""bench.py's line must survive whatever happens to the process that measures (harness/guardian.py).
+
+Round 4's driver run ended with SIGABRT from a c10d watchdog thread inside an optional leg, 50 s after the headline had been
+measured: no line, no measurement.  These tests run the same two-process shape on CPU with a worker (tests/fake_bench.py)
+that aborts, exits, hangs or raises on purpose, alone and as one of two gloo ranks under torch.distributed.run.
+"""
+import json
+import os
+import signal
+import subprocess
+import sys
+import time
+
+import pytest
+
+from harness import launch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FAKE = os.path.join(HERE, 'fake_bench.py')
+
+
+def run(*argv, timeout=120, env=None):
+    e = {k: v for k, v in (env or os.environ).items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, FAKE] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=e)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    return p, lines
+
+
+def test_clean_run_prints_exactly_one_line():
+    p, lines = run()
+    assert p.returncode == 0, p.stderr
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['value'] == 123.0 and d['a'] == d['b'] == d['c'] == 'ok'
+    assert d['bench_process']['restarts'] == 0 and d['bench_process']['workers'] == [{'exit': 0, 'legs_done': 4}]
+    assert list(d)[-1] == 'roofline'                     # the driver keeps the tail of the line
+
+
+@pytest.mark.parametrize('how,shown', [('abort', 'SIGABRT'), ('exit', 7), ('raise', 1)])
+def test_a_worker_that_dies_in_a_leg_costs_that_leg_only(how, shown):
+    p, lines = run('--die-in', 'b', '--how', how)
+    assert p.returncode == 0, p.stderr
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d['value'] == 123.0 and d['a'] == 'ok' and d['c'] == 'ok' and 'b' not in d
+    bp = d['bench_process']
+    assert bp['restarts'] == 1 and len(bp['workers']) == 2
+    assert bp['workers'][0]['exit'] == shown and bp['workers'][0]['during'] == 'b' and bp['workers'][1]['exit'] == 0
+    assert 'b' in bp['legs_lost_with_their_worker'] and str(shown) in bp['legs_lost_with_their_worker']['b']
+    assert d['lost'] == bp['legs_lost_with_their_worker']       # the fresh worker was told
+
+
+def test_the_last_leg_dying_needs_no_restart():
+    p, lines = run('--die-in', 'c')
+    assert p.returncode == 0 and len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['a'] == d['b'] == 'ok' and 'c' not in d and d['bench_process']['restarts'] == 0
+
+
+def test_dying_before_the_headline_is_an_error_line_and_a_nonzero_exit():
+    p, lines = run('--die-in', 'headline')
+    assert p.returncode == 1 and len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['value'] is None and 'SIGABRT' in d['error']
+
+
+def test_a_hanging_leg_is_ended_at_the_wall_limit_with_the_line_intact():
+    t0 = time.time()
+    p, lines = run('--die-in', 'b', '--how', 'hang', '--deadline-s', '3')
+    assert time.time() - t0 < 30
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout, p.stderr)
+    d = json.loads(lines[0])
+    assert d['value'] == 123.0 and d['a'] == 'ok' and 'b' not in d and 'wall limit' in d['error']
+    assert d['bench_process']['workers'][-1]['during'] == 'b'
+
+
+def test_multi_rank_runs_are_not_restarted_and_other_ranks_stay_silent():
+    p, lines = run('--die-in', 'b', '--world', '2', '--rank', '0')
+    assert p.returncode == 0 and len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['a'] == 'ok' and 'c' not in d and d['bench_process']['restarts'] == 0
+    p, lines = run('--die-in', 'b', '--world', '2', '--rank', '1')
+    assert p.returncode == 0 and lines == []               # a non-zero exit would make torchrun tear rank 0 down before it prints
+
+
+def test_sigterm_to_the_guardian_prints_the_line_and_ends_the_worker():
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.Popen([sys.executable, FAKE, '--die-in', 'c', '--how', 'hang'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+    time.sleep(3.0)                                        # headline, a, b are done by now; c hangs
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert p.returncode == 0 and len(lines) == 1, (out, err)
+    d = json.loads(lines[0])
+    assert d['value'] == 123.0 and d['b'] == 'ok' and 'c' not in d
+    assert 'SIGTERM' in d['bench_process']['workers'][-1]['exit']
+
+
+def test_rank_1_killed_with_sigabrt_mid_leg_rank_0_still_prints_the_headline():
+    """Two gloo ranks under torch.distributed.run, each a guardian + worker pair.  Rank 1's worker aborts inside leg 'a' while
+    rank 0 is in that leg's all-reduce: rank 0's collective gives up at the data group's timeout (4 s here, DATA_TIMEOUT_S =
+    120 s in bench.py), the leg is recorded as failed, the later collective-bearing legs are skipped, and rank 0's guardian
+    prints ONE line with the headline; the launcher exits 0."""
+    t0 = time.time()
+    rc, out = launch.run_ranks(FAKE, 2, ['--dist', '--die-in', 'a', '--die-rank', '1'], timeout=240, capture=True)
+    took = time.time() - t0
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert rc == 0, out[-3000:]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d['value'] == 123.0 and d['n_gpus'] == 2
+    assert 'error' in d['a'] and 1 in d['a']['failed_ranks']
+    assert 'skipped' in d['b'] and 'skipped' in d['c']
+    assert took < 120, took
+
+
+def test_bench_py_guardian_never_imports_torch():
+    """The process that owns the line must not be able to die of torch / HIP / RCCL: bench.py's guardian path imports the
+    standard library and harness.guardian / harness.launch only."""
+    code = ("import sys; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench, harness.guardian, harness.launch; "
+            "assert 'torch' not in sys.modules, 'torch imported'; print('ok')" % ROOT)
+    p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == 'ok', p.stderr
+
+
+def test_bench_legs_and_budget_table_are_consistent():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert set(bench.OPTIONAL) <= set(bench.LEGS) and set(bench.DISTILL_LEGS) <= set(bench.LEGS)
+    assert bench.LEGS.index('cpu_baseline') < bench.LEGS.index('kernels') < bench.LEGS.index('cifar_student')
+    first_optional = min(bench.LEGS.index(x) for x in bench.OPTIONAL)
+    assert first_optional > bench.LEGS.index('cifar_student')       # nothing optional before the legs the metric names
+    args = bench.parse_args(['--gpus', '8'])
+    off = bench.disabled_legs(args, 8)
+    assert {'cifar_graph', 'rocprof', 'cpu_baseline', 'pcie_note', 'cpu_distill'} <= off       # N > 1: no capture next to live collectives
+    assert 'cifar_graph' not in bench.disabled_legs(bench.parse_args(['--gpus', '8', '--graph-at-any-n']), 8)
+    assert bench.disabled_legs(bench.parse_args([]), 1) == set()

@@ -1,0 +1,45 @@
+"""hipGraph capture next to a live RCCL process group (harness/distill.py: capture_into, quiesce_collectives).
+
+Round 4's driver-run bench was lost here: the c10d watchdog thread polled a collective's completion event while a
+GLOBAL-mode capture was open on the main thread -> "operation not permitted when stream is capturing" on the watchdog ->
+std::terminate -> SIGABRT.  The product now captures in thread-local mode, after waiting for its collectives and giving
+the watchdog time to retire them, and restores the caller's stream if a capture fails.  Each case runs in a child process
+(tests/capture_worker.py): the failure mode is a process abort.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_worker(*argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    return subprocess.run([sys.executable, os.path.join(HERE, 'capture_worker.py')] + list(argv), env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_capture_right_after_20_allreduce_steps_30_times_over():
+    """The driver's situation, x 30: one-rank NCCL group, forced collectives, 20 eager steps, capture immediately."""
+    p = run_worker('--iters', '30', '--steps', '20')
+    assert p.returncode == 0, 'rc %s\n%s' % (p.returncode, p.stderr[-3000:])
+    assert 'CAPTURE_OK 30' in p.stdout
+
+
+def test_thread_local_capture_holds_with_collectives_in_flight_and_no_settling():
+    """The capture mode on its own: no settling time, and 8 un-waited all-reduces issued right before every capture, so the
+    watchdog is polling completion events while the capture is open."""
+    p = run_worker('--iters', '20', '--steps', '20', '--settle', '0', '--inflight', '8')
+    assert p.returncode == 0, 'rc %s\n%s' % (p.returncode, p.stderr[-3000:])
+    assert 'CAPTURE_OK 20' in p.stdout
+
+
+def test_a_failed_capture_restores_the_stream_and_leaves_an_eager_trainer():
+    """capture_into(): when the captured body fails, the stream that was current before is current again and the next launches
+    work; the trainer has not switched to replay, still steps eagerly, and can be captured later."""
+    p = run_worker('--failed-capture')
+    assert p.returncode == 0, 'rc %s\n%s' % (p.returncode, p.stderr[-3000:])
+    assert 'FAILED_CAPTURE_OK' in p.stdout

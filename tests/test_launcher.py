@@ -42,14 +42,16 @@ def test_launcher_command_shape():
 
 def test_bench_relaunches_itself_for_n_gt_1():
     """bench.py reads --gpus, and with N > 1 outside a launcher hands over to launch.run_ranks
-    BEFORE touching the GPU; the launched ranks then report dist.get_world_size()."""
+    BEFORE anything touches the GPU (the guardian process never does; the device count is asked of a child);
+    the launched ranks then report the world size they were given."""
     src = open(os.path.join(ROOT, 'bench.py')).read()
-    main = src[src.index('def main():'):]
-    i_launch = main.index('launch.run_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:])')
-    assert 'args.gpus > 1 and not launch.under_launcher()' in main[:i_launch]
-    assert i_launch < main.index('torch.cuda.set_device')
-    assert "'rccl_world_size': rccl_world_size" in main and 'dist.get_world_size()' in main
-    assert "'n_gpus': n_gpus" in main
+    g = src[src.index('def guardian_main('):src.index('def worker_main(')]
+    i_launch = g.index('launch.run_ranks(os.path.abspath(__file__), args.gpus, argv)')
+    assert 'args.gpus > 1 and not launch.under_launcher()' in g[:i_launch]
+    assert i_launch < g.index('guardian.supervise(')
+    assert 'import torch' not in g.replace("'import torch; print(", '')         # only inside the child's -c string
+    w = src[src.index('def worker_main('):]
+    assert "'n_gpus': n_gpus" in w and "group['world'] = dist.get_world_size()" in w
 
 
 def test_bench_without_gpu_with_n_gt_1_fails_loudly():

@@ -20,6 +20,8 @@
 #   kprof      tools/bench_kernels.py --no-sweeps under rocprofv3 --kernel-trace --stats
 #   coverage   tools/launch_coverage.py --run: the GPU suite under rocprofv3 --kernel-trace --stats, shipped kernels never launched
 #   dispatch   tools/dispatch_map.py --trace: call geometry -> kernel map
+#   driver     the driver's exact command (python3 bench.py --gpus 1 --steps 20 --warmup 5), output numbered by DRIVER_TAG (soak: one per lease)
+#   capture    tests/test_hip_capture_watchdog.py, then the round-4 configuration on purpose (global-mode capture, collectives in flight)
 set +e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
@@ -79,6 +81,28 @@ for step in "$@"; do
              find gpurun_out/spread_trace -name '*.csv' -size +8M -delete ;;
     coverage) timeout 3000 python tools/launch_coverage.py --run > gpurun_out/launch_coverage.log 2>&1; echo "coverage rc=$?"; head -40 gpurun_out/launch_coverage.txt; tail -5 gpurun_out/launch_coverage.log ;;
     dispatch) timeout 1200 python tools/dispatch_map.py --trace > gpurun_out/dispatch_map.log 2>&1; echo "dispatch rc=$?"; head -30 gpurun_out/dispatch_map.txt; tail -3 gpurun_out/dispatch_map.log ;;
+    driver)  tag=${DRIVER_TAG:-1}; t0=$(date +%s%N)
+             timeout 1700 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver_$tag.json 2> gpurun_out/bench_driver_$tag.err; rc=$?
+             t1=$(date +%s%N); echo "driver command rc=$rc wall=$(( (t1 - t0) / 1000000 )) ms lines=$(wc -l < gpurun_out/bench_driver_$tag.json)"
+             python - <<PYEOF
+import json
+d = json.loads(open('gpurun_out/bench_driver_$tag.json').read().strip().splitlines()[-1])
+r = d['roofline']
+print('value', d['value'], 'frac', r['frac'], 'rocprof_frac', r.get('rocprof_frac'), 'traffic', r.get('traffic_over_algorithmic'), 'cpu', (d.get('cpu_baseline') or {}).get('value'), (d.get('cpu_baseline') or {}).get('kind'))
+print('kernel rows', len(r.get('kernels') or []), '| parity', d.get('parity_bit_exact_vs_reference'), d.get('parity_bit_exact_vs_oracle'))
+print('legs', r.get('legs_wall_s'), '| wall', r.get('wall_s'))
+print('process', d.get('bench_process'))
+for k in r:
+    if k.startswith('steps_') or k.startswith('dp_'):
+        print(k, r[k])
+PYEOF
+             ;;
+    capture) timeout 1500 python -m pytest tests/test_hip_capture_watchdog.py -q -m gpu > gpurun_out/capture_tests.log 2>&1; echo "capture tests rc=$?"; tail -3 gpurun_out/capture_tests.log
+             # what round 4 ran, provoked: global-mode capture with collectives in flight -- expected to die (SIGABRT = rc 134)
+             timeout 600 python tests/capture_worker.py --mode global --settle 0 --inflight 8 --iters 20 > gpurun_out/capture_global_mode.log 2>&1; echo "global-mode capture, collectives in flight: rc=$?"
+             grep -m3 "capturing\|CAPTURE_OK\|terminate" gpurun_out/capture_global_mode.log | cut -c1-300
+             timeout 600 python tests/capture_worker.py --mode global --settle 0.35 --iters 20 > gpurun_out/capture_global_mode_settled.log 2>&1; echo "global-mode capture after quiescing: rc=$?"
+             grep -m3 "capturing\|CAPTURE_OK\|terminate" gpurun_out/capture_global_mode_settled.log | cut -c1-300 ;;
     *)       echo "unknown step $step" ;;
   esac
 done
