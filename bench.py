@@ -63,7 +63,7 @@ if ROOT not in sys.path:
 # the default run, in order; everything after 'cifar_student' is optional (wall budget)
 LEGS = ['headline', 'rocprof', 'cpu_baseline', 'kernels', 'cifar_student',
         'cifar_graph', 'pcie_note', 'diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp', 'cpu_distill']
-OPTIONAL = {'cifar_graph': 9, 'pcie_note': 3, 'diffquant_wrn': 22, 'imagenet_resnet18k_dp': 14, 'nmt_lstm_dp': 12, 'cpu_distill': 12}
+OPTIONAL = {'cifar_graph': 4, 'pcie_note': 1, 'diffquant_wrn': 50, 'imagenet_resnet18k_dp': 20, 'nmt_lstm_dp': 15, 'cpu_distill': 12}
 #            ^ seconds a leg is expected to take on an MI355X box (profiles/r05_bench*.json legs_wall_s): it starts only if that fits the budget
 DISTILL_LEGS = ('cifar_student', 'cifar_graph', 'diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp')
 
@@ -80,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-dp-configs', action='store_true', help='skip the ImageNet-shaped and seq2seq steps/sec legs')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 child processes (kernel duration + PMC HBM traffic of the headline kernel)')
-    ap.add_argument('--budget-s', type=float, default=90.0,
+    ap.add_argument('--budget-s', type=float, default=150.0,
                     help='wall budget of the run: an OPTIONAL leg starts only if its expected duration still fits (0: no limit)')
     ap.add_argument('--deadline-s', type=float, default=1500.0,
                     help='after this many seconds the guardian ends the worker and prints the line with what has been measured so far')

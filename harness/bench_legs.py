@@ -74,7 +74,7 @@ def cpu_baseline(x_host, q_gpu, alpha_gpu, budget_s=2.0, with_ports=True):
         # torch's elementwise CPU ops oversubscribe badly with one thread per SMT sibling on a 2-socket box
         # (0.3 GB/s at 256 threads in round 1), so the reference is timed at several thread counts and the BEST is
         # the baseline; os.cpu_count() threads -- what the survey prescribes -- is always among them (bounded: a count
-        # whose single run takes over a second gets two timed runs, not five).
+        # whose single run takes about a second or more gets ONE timed run after its warm-up, not five).
         counts = sorted({ncpu, min(ncpu, 64), min(ncpu, 32)}, reverse=True)
         per_threads, best = {}, None
         for th in counts:
@@ -82,7 +82,7 @@ def cpu_baseline(x_host, q_gpu, alpha_gpu, budget_s=2.0, with_ports=True):
             t0 = time.perf_counter()
             refq.uniformQuantization(x_host, LEVELS, bucket_size=BUCKET)            # warm-up, and a first idea of the cost
             first = time.perf_counter() - t0
-            ts = _time_runs(lambda: refq.uniformQuantization(x_host, LEVELS, bucket_size=BUCKET), 2 if first > 0.8 else 5,
+            ts = _time_runs(lambda: refq.uniformQuantization(x_host, LEVELS, bucket_size=BUCKET), 1 if first > 0.8 else 5,
                             budget_s, warm=False)
             per_threads[str(th)] = {'min_s': round(min(ts), 4), 'median_s': round(float(np.median(ts)), 4), 'runs': len(ts),
                                     'GBps_at_min': round(ALGO_BYTES_PER_ELEM * n / min(ts) / 1e9, 3)}
@@ -354,12 +354,15 @@ def dp_config_steps_per_sec(kind, dev, rank, n_gpus, distributed, ctl_barrier, s
         desc = ('multi30k-shaped synthetic tokens (len 20..50, V_src 18000, V_tgt 10000), 2-layer LSTM 500/500 with input '
                 'feeding + general attention (22 tensors, 28.8 M), teacher of the same shape, word-level KD 0.3 NLL + 0.7 KL; '
                 'SGD lr 1.0, clip-norm 5; 4-bit uniform, bucket 256')
+    t_w = time.perf_counter()
     for i in range(warmup):
         tr.step(*batches[i % 2])
+    torch.cuda.synchronize()
+    warmup_s = time.perf_counter() - t_w
 
     def set_exchange(on):
         tr.sync.active = on and tr.sync.world_active
-    out = {'config': desc}
+    out = {'config': desc, 'warmup_s (first use: MIOpen searches its plans for these shapes)': round(warmup_s, 1)}
     out.update(dp_report(lambda i: tr.step(*batches[i % 2]), steps, reps, dev, n_gpus, distributed, per_gpu,
                          tr.flat_grad.numel() * 4, set_exchange, tr.sync.sync if tr.sync.active else None, ctl_barrier, rank))
     out['gradient_bytes_per_step'] = int(tr.flat_grad.numel() * 4)
@@ -393,8 +396,11 @@ def diffquant_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=8
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     x, y = synthetic_batch(batch, dev, seed=11 + 1000 * rank)
+    t_w = time.perf_counter()
     for _ in range(warmup):
         tr.step(x, y)
+    torch.cuda.synchronize()
+    warmup_s = time.perf_counter() - t_w
     exchanging = tr.exchange
 
     def set_exchange(on):
@@ -410,6 +416,7 @@ def diffquant_steps_per_sec(dev, rank, n_gpus, distributed, ctl_barrier, steps=8
                          tr.points_grad.numel() * 4 if exchanging else 0, set_exchange, exchange_once if exchanging else None,
                          ctl_barrier, rank))
     out['setup_s'] = round(setup_s, 2)
+    out['warmup_s (first use: MIOpen searches its plans for these shapes)'] = round(warmup_s, 1)
     ph = {'assign_all_tensors_ms (multi-tensor K5, 1 launch)': round(event_ms(tr.quantize, 50), 4),
           'fwd_bwd_ms': round(event_ms(lambda: tr.forward_backward(x, y), 3, precondition_s=0.0, reps=2), 3),
           'point_gradients_ms (multi-tensor K6, 2 launches)': round(event_ms(tr.point_gradients, 50), 4),

@@ -190,6 +190,7 @@ class DistillTrainer(object):
 
     # ------------------------------------------------------------------ hipGraph replay of the step
     _graph_fb = None
+    _capture_failed = False
 
     def capture(self, *batch, warmup=3, error_mode='thread_local', settle_s=0.35, _before_capture=None):
         """Capture the launch-bound part of the step in hipGraphs (torch.cuda.CUDAGraph): graph A =
@@ -205,6 +206,10 @@ class DistillTrainer(object):
         Safe next to a live RCCL process group (see capture_into / quiesce_collectives below): the capture is thread-local, the
         collectives issued so far have been waited for and retired, and a capture that fails restores the caller's stream and
         leaves this an eager trainer."""
+        if self._capture_failed:
+            # (measured: capturing again on a trainer whose earlier capture_shapes() died half-way ends in a segmentation fault
+            # inside the runtime -- profiles/r05_capture_probe.txt; a fresh trainer in the same process captures fine)
+            raise RuntimeError('an earlier capture on this trainer failed: discard it and capture on a fresh one')
         assert self.mode == 'multi', 'graph capture needs the persistent-shadow (multi) mode'
         assert self.style == 'none' and self.every == 1 and self._since >= 1, \
             'graph capture covers the plain every-step STE loop only'
@@ -247,6 +252,7 @@ class DistillTrainer(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         del saved_master, saved_buffers, saved_momenta
+        self._capture_failed = True                      # until the whole set of graphs exists
         quiesce_collectives(self.sync, settle_s)
         if _before_capture is not None:                  # test hook (tests/capture_worker.py: collectives in flight on purpose)
             _before_capture()
@@ -269,6 +275,7 @@ class DistillTrainer(object):
         # only a COMPLETE set of graphs switches the trainer to replay: a capture that raised leaves it an eager trainer
         self._graphs = graphs
         self._graph_fb, self._graph_opt = graphs, gb
+        self._capture_failed = False
 
     def _step_graph(self, *batch):
         entry = self._graphs.get(tuple(tuple(t.shape) for t in batch))

@@ -37,9 +37,31 @@ def test_thread_local_capture_holds_with_collectives_in_flight_and_no_settling()
     assert 'CAPTURE_OK 20' in p.stdout
 
 
-def test_a_failed_capture_restores_the_stream_and_leaves_an_eager_trainer():
-    """capture_into(): when the captured body fails, the stream that was current before is current again and the next launches
-    work; the trainer has not switched to replay, still steps eagerly, and can be captured later."""
-    p = run_worker('--failed-capture')
+def test_long_thread_local_capture_with_an_incomplete_allreduce_listed_by_the_watchdog():
+    """Deterministic form: ONE capture held open for 0.5 s while an all-reduce is kept incomplete behind a spin kernel, so the
+    watchdog (100 ms period) queries that work item's event several times while the capture is open.  Thread-local mode
+    (what capture_into() uses): passes."""
+    p = run_worker('--long-capture', '0.5', '--mode', 'thread_local')
     assert p.returncode == 0, 'rc %s\n%s' % (p.returncode, p.stderr[-3000:])
+    assert 'LONG_CAPTURE_OK' in p.stdout
+
+
+def test_the_same_capture_in_global_mode_is_round_4s_crash():
+    """... and in torch's default 'global' mode the same situation IS the crash that cost round 4 its driver measurement: the
+    watchdog thread's event query is refused ("operation not permitted when stream is capturing"), its exception ends the
+    process with SIGABRT.  Kept as a test so that the hazard stays documented by something that runs; if a later torch / HIP
+    makes global mode survive this, the assertion below is what to delete."""
+    p = run_worker('--long-capture', '0.5', '--mode', 'global')
+    assert p.returncode != 0 and 'LONG_CAPTURE_OK' not in p.stdout
+    assert 'stream is capturing' in p.stderr and 'watchdog' in p.stderr, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize('how', ['raise', 'sync', 'item'])
+def test_a_failed_capture_restores_the_stream_and_leaves_the_process_usable(how):
+    """capture_into(): when the captured body fails (a Python exception; a device synchronize or a blocking copy, which
+    invalidate the capture so that capture_end() raises too), the stream that was current before is current again, eager
+    launches work, the trainer has not switched to replay and still steps eagerly (further capture attempts on it are refused:
+    it is to be discarded), and fresh captures -- a simple graph, a new trainer -- work in the same process."""
+    p = run_worker('--failed-capture', how)
+    assert p.returncode == 0, 'rc %s\n%s\n%s' % (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
     assert 'FAILED_CAPTURE_OK' in p.stdout
