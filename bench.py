@@ -275,6 +275,8 @@ def worker_main(args):
                 done.append(name)
                 return
         snapshot(running=name)
+        if os.environ.get('QD_BENCH_TEST_ABORT_IN') == name and not resume:        # test hook (tests/test_hip_bench_ranks.py):
+            os.abort()                                                             # what a watchdog thread's std::terminate does
         t0 = time.time()
         res = runner.run(name, fn, collective=collective)
         torch.cuda.empty_cache()

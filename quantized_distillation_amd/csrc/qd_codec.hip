@@ -431,22 +431,26 @@ __global__ __launch_bounds__(256) void k_hist_sym(const void* data, int64_t n, i
 
 // Level histogram of x in ONE pass (4 B read per element, nothing written but the counters): the quantize half of
 // k_pack_vec -- a bucket in registers, min / max by DPP or wave reduction, level = rint((x - beta) / alpha * (s - 1)) --
-// feeding the [levels + 1][32] LDS counter table of k_hist_atomic instead of a store.  What codec.level_histogram (the
+// feeding a [levels][32] LDS counter table (the layout of k_hist_atomic's, without its out-of-range row) instead of a store.  What codec.level_histogram (the
 // Huffman accounting of a model in its own packed format) needs: the level indices themselves never reach memory.
 // Persistent grid: the table is zeroed and flushed once per block.  The short last bucket is done by block 0's first wave.
 template <int LPB, int V>
 __global__ __launch_bounds__(256) void k_level_hist_vec(const float* x, int64_t nvec, int64_t n, float sm1, int levels,
                                                         unsigned long long* partial /* [levels][gridDim.x] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hist_lds[];
-    uint32_t* cnt = (uint32_t*)hist_lds;                                   // [levels + 1][32], row `levels` = dummy (NaN buckets)
+    uint32_t* cnt = (uint32_t*)hist_lds;                                   // [levels][32]: 32 column copies of every counter (bank spread)
     constexpr int BPW = 64 / LPB;
     constexpr int ROW = LPB * V * 4;
-    for (int j = threadIdx.x; j < (levels + 1) * 32; j += 256) cnt[j] = 0;
+    for (int j = threadIdx.x; j < levels * 32; j += 256) cnt[j] = 0;
     __syncthreads();
     uint32_t* col = cnt + (threadIdx.x & 31);
     const float top = (float)levels;
-    auto bump = [&](float lev) {                                           // lev: an integer in [0, levels - 1]; NaN (a bucket that holds one) counts as
-        const uint32_t li = (lev >= 0.0f && lev < top) ? (uint32_t)(int)lev : 0u;      // level 0, which is what the uint8 level output stores for it
+    // lev: an integer in [0, levels - 1], or NaN -- every element of a bucket that holds a NaN, and the +-inf elements (and, for
+    // a -inf minimum, all elements) of a bucket that holds an infinity (alpha = inf: (x - beta) / alpha is 0 or NaN).  NaN counts
+    // as level 0: what the uint8 level output of the quantize kernel stores for it ((uint8)(int)NaN = 0), so this one-pass form
+    // and the write-levels-then-count form agree on such tensors too (tests/test_hip_huffman.py, the non-finite case).
+    auto bump = [&](float lev) {
+        const uint32_t li = (lev >= 0.0f && lev < top) ? (uint32_t)(int)lev : 0u;
         __hip_atomic_fetch_add(col + li * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     const int lane = threadIdx.x & 63;
@@ -706,7 +710,7 @@ int qd_level_histogram_f32(const float* x, int64_t n, int64_t bucket, int levels
     }
     if (!workspace || (((uintptr_t)workspace) & 7)) return QD_ERR_WORKSPACE_TOO_SMALL;
     const int64_t nfull = n / bucket;
-    const size_t lds = (size_t)(levels + 1) * 32 * sizeof(uint32_t);
+    const size_t lds = (size_t)levels * 32 * sizeof(uint32_t);
     const float sm1 = (float)(levels - 1);
 #define QD_LH(LPB, V)                                                                                                 \
     {                                                                                                                 \

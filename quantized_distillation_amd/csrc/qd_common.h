@@ -53,11 +53,11 @@ inline int device_cus() {
     static int cache[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
-    const int slot = dev & 63;
-    int v = __atomic_load_n(&cache[slot], __ATOMIC_RELAXED);
+    const bool cached = dev >= 0 && dev < 64;                  // a device index beyond the table is asked every time, never aliased
+    int v = cached ? __atomic_load_n(&cache[dev], __ATOMIC_RELAXED) : 0;
     if (v == 0) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
-        if (dev < 64) __atomic_store_n(&cache[slot], v, __ATOMIC_RELAXED);
+        if (cached) __atomic_store_n(&cache[dev], v, __ATOMIC_RELAXED);
     }
     return v;
 }

@@ -1903,8 +1903,9 @@ int fused_capacity() {                                         // blocks of k_si
     static int caps[64];                                       // per device, stored + 1 (0 = not asked yet)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    int& slot = caps[dev & 63];
-    int cap = __atomic_load_n(&slot, __ATOMIC_RELAXED) - 1;
+    const bool cached = dev >= 0 && dev < 64;                  // a device index beyond the table is asked every time, never aliased
+    int& slot = caps[cached ? dev : 0];
+    int cap = cached ? __atomic_load_n(&slot, __ATOMIC_RELAXED) - 1 : -1;
     if (cap < 0) {
         int per_cu = 0;
         hipFuncAttributes fa;
@@ -1915,7 +1916,7 @@ int fused_capacity() {                                         // blocks of k_si
         (void)hipGetLastError();
         int c = per_cu * num_cus();
         cap = c > kFusedMaxBlocks ? kFusedMaxBlocks : c;
-        if (dev < 64) __atomic_store_n(&slot, cap + 1, __ATOMIC_RELAXED);
+        if (cached) __atomic_store_n(&slot, cap + 1, __ATOMIC_RELAXED);
     }
     return cap;
 }

@@ -240,7 +240,7 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
     (non-uniform), count the symbols -- but the counting runs on the device: the reference copies every quantized tensor
     to the host for np.digitize + np.unique (:215-223); here the digitize + histogram is one kernel over the re-scaled
     tensor (qd_digitize_histogram_f32, same float64 comparison against the same edges) or over the int64 indices
-    (qd_histogram_i64), and only the s + 1 (k + 1) counters cross PCIe.  Tensors that cannot take that path (more than 256
+    (qd_histogram_i64), and only the s + 1 (k + 1) counters cross PCIe -- once per device, after the last tensor.  Tensors that cannot take that path (more than 256
     symbols, or a quantization function that returns host tensors) are counted on the host exactly as before."""
     type_quantization = type_quantization.lower()
     if type_quantization not in ('uniform', 'nonuniform'):
@@ -255,6 +255,7 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
     tol = 1e-5
     edges = _digitize_edges(s, tol) if type_quantization == 'uniform' else None
     edges_dev, device_totals = {}, {}           # per device: the edges, the running int64 counters (uniform)
+    index_hists = {}                            # per device: [(counters of one tensor, its quantization function, the tensor)] (non-uniform)
 
     def host_count(bins):
         for value, count in zip(*np.unique(bins, return_counts=True)):
@@ -281,16 +282,23 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
             _, bins, _ = fn(param)
             bins = bins.view(-1)
             hist = _device_counts('index', bins, DEVICE_HISTOGRAM_MAX_SYMBOLS)
-            h = hist.cpu().numpy() if hist is not None else None
-            if h is not None and h[-1] == 0:                 # (last counter: indices outside the table -- then count on the host)
-                for value in np.nonzero(h[:-1])[0]:
-                    counts[int(value)] += int(h[value])
-            else:
+            if hist is None:
                 host_count(bins.cpu().numpy())
+            else:                                            # stays on the device: ONE copy per device at the end, not one per tensor
+                index_hists.setdefault(bins.device, []).append((hist, fn, param))
     for hist in device_totals.values():
         h = hist.cpu().numpy()
         for c in np.nonzero(h)[0]:
             counts[int(c) - 1] += int(h[c])
+    for pending in index_hists.values():
+        table = torch.stack([h for h, _fn, _p in pending]).cpu().numpy()       # [tensors, MAX_SYMBOLS + 1]
+        fine = table[:, -1] == 0                             # last counter: indices outside the table
+        h = table[fine, :-1].sum(axis=0)
+        for value in np.nonzero(h)[0]:
+            counts[int(value)] += int(h[value])
+        for (_h, fn, param), ok in zip(pending, fine):       # the tensors with such indices: counted on the host, as the reference does
+            if not ok:
+                host_count(fn(param)[1].view(-1).cpu().numpy())
     assert total == sum(counts.values())
     freq = {sym: c / total for sym, c in counts.items()}
     return sum(freq[sym] * len(code) for sym, code in huffman_encode(freq))

@@ -70,3 +70,28 @@ def test_a_failed_preflight_collective_still_yields_the_line():
     assert d['n_gpus'] == 2 and d['value'] > 0
     for name, leg in d['distill'].items():
         assert 'skipped' in leg and 'pre-flight' in leg['skipped'], (name, leg)
+
+
+def test_a_leg_that_aborts_the_worker_costs_that_leg_only():
+    """The round-4 failure, injected: the worker process dies with SIGABRT inside the optional hipGraph leg (after the headline,
+    the kernel rows and the configs[1] leg).  The guardian (harness/guardian.py) records the leg as lost, starts a fresh worker
+    for the legs that are left, and prints ONE line with everything else in it; exit code 0."""
+    env = dict(os.environ, QD_BENCH_TEST_ABORT_IN='cifar_graph')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--quick', '--no-pmc',
+                        '--precondition-s', '0.05', '--skip-legs', 'diffquant_wrn,nmt_lstm_dp,imagenet_resnet18k_dp,kernels'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['value'] > 0 and d['roofline']['frac'] > 0 and d['cpu_baseline']['value'] > 0
+    bp = d['bench_process']
+    assert bp['restarts'] == 1 and bp['workers'][0]['exit'] == 'SIGABRT' and bp['workers'][0]['during'] == 'cifar_graph' and bp['workers'][1]['exit'] == 0
+    assert 'cifar_graph' in bp['legs_lost_with_their_worker']
+    assert 'multi' in d['distill']['cifar_student']                         # measured by the first worker, kept
+    assert 'SIGABRT' in d['distill']['cifar_graph']['error']                # the lost leg says so
+    assert d['roofline']['pcie_inclusive_GBps_note'] > 0                    # measured by the second worker
+    assert d['cpu_baseline']['distill']['steps_per_sec'] > 0
+    assert list(d)[-1] == 'roofline'

@@ -205,6 +205,31 @@ def test_levels_only_form_of_the_quantize_kernel():
     for s, bucket in ((16, 256), (16, 100), (4, None), (256, 2048)):
         assert np.array_equal(host(codec.level_histogram(dev(xh), s, bucket)), np.bincount(oc.uniform_quantize(xh, s, bucket)['lev'], minlength=s))
     assert np.array_equal(host(codec.level_histogram(dev(xh)[1:], 16, 256)), np.bincount(oc.uniform_quantize(xh[1:], 16, 256)['lev'], minlength=16))
+    # non-finite buckets: the one-pass form (qd_level_histogram_f32) and the write-the-levels-then-count form must give the same
+    # counts -- a NaN anywhere in a bucket, +inf, -inf, both, in full buckets and in the short last one
+    xn = rng.randn(256 * 40 + 77).astype(np.float32)
+    xn[5] = np.nan
+    xn[256 * 3 + 17] = np.inf
+    xn[256 * 7 + 1] = -np.inf
+    xn[256 * 9 + 2], xn[256 * 9 + 200] = np.inf, -np.inf
+    xn[256 * 11:256 * 12] = np.inf
+    xn[-3] = np.inf
+    xd = dev(xn)
+    one_pass = host(codec.level_histogram(xd, 16, 256))
+    lev = torch.empty(xn.size, dtype=torch.uint8, device=DEV)
+    q = torch.empty_like(xd)
+    _lib.check(lib.qd_uniform_f32(xd.data_ptr(), q.data_ptr(), xn.size, 256, 16, None, None, lev.data_ptr(), None, 0, 0.0, 0, 0,
+                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    two_pass = host(codec.histogram_u8(lev, 16))
+    assert one_pass.sum() == xn.size and np.array_equal(one_pass, two_pass), (one_pass, two_pass)
+    assert np.array_equal(two_pass, np.bincount(host(lev), minlength=16))
+    # the buckets that hold a non-finite value count as level 0 throughout
+    finite_buckets = np.ones(41, bool)
+    finite_buckets[[0, 3, 7, 9, 11, 40]] = False
+    ref = oc.uniform_quantize(xn[:256 * 40].reshape(40, 256)[finite_buckets[:40]].reshape(-1), 16, 256)['lev']
+    want = np.bincount(ref, minlength=16)
+    want[0] += xn.size - ref.size
+    assert np.array_equal(one_pass, want), (one_pass, want)
 
 
 def test_kernels_that_write_in_place_bump_the_version_counter():
