@@ -18,7 +18,8 @@ once, when the worker has ended -- however it ended.  Round 4's driver run was l
 in an optional leg 50 s after the headline had been measured; now a dying leg costs that leg: the
 guardian records it, starts a fresh worker for the legs that are left (N = 1) and prints the line.
 
-Order of the legs (N = 1: the whole default run is sized to finish in about 90 s):
+Order of the legs (N = 1: the whole default run takes ~95 s on a fresh box, 41 s of which are MIOpen's first-use search for the
+WideResNet-16-22 convolution shapes inside the diffquant_wrn leg -- its `warmup_s`):
   headline        the timed region of the contract (+ the kernel's HIP-event time -> roofline)
   rocprof         the same kernel under rocprofv3 in child processes: --kernel-trace duration, PMC HBM traffic
   cpu_baseline    the REFERENCE's own uniformQuantization on the host cores, same workload; checker of the GPU result
@@ -63,7 +64,7 @@ if ROOT not in sys.path:
 # the default run, in order; everything after 'cifar_student' is optional (wall budget)
 LEGS = ['headline', 'rocprof', 'cpu_baseline', 'kernels', 'cifar_student',
         'cifar_graph', 'pcie_note', 'diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp', 'cpu_distill']
-OPTIONAL = {'cifar_graph': 4, 'pcie_note': 1, 'diffquant_wrn': 50, 'imagenet_resnet18k_dp': 20, 'nmt_lstm_dp': 15, 'cpu_distill': 12}
+OPTIONAL = {'cifar_graph': 4, 'pcie_note': 1, 'diffquant_wrn': 50, 'imagenet_resnet18k_dp': 4, 'nmt_lstm_dp': 9, 'cpu_distill': 12}
 #            ^ seconds a leg is expected to take on an MI355X box (profiles/r05_bench*.json legs_wall_s): it starts only if that fits the budget
 DISTILL_LEGS = ('cifar_student', 'cifar_graph', 'diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp')
 

@@ -215,9 +215,12 @@ typedef struct QdDiffQuantDesc {
     const float* grad;    /* dLoss/dq [n] (backward only)                                  */
     int64_t n;
     int64_t first_tile;   /* filled by qd_multi_dq_plan: prefix of 4-bucket tiles (forward) */
-    int64_t first_block;  /* filled by qd_multi_dq_plan: prefix of reduction blocks        */
+    int64_t first_block;  /* filled by qd_multi_dq_plan: prefix of FULL 1024-element gradient tiles (backward) */
 } QdDiffQuantDesc;
-/* Host helper: fills first_tile / first_block, returns total tiles, writes the total block count. */
+/* Host helper: fills first_tile / first_block, returns the total of forward tiles, writes `total_blocks` = the number of
+ * partial rows of the backward sweep, ntensors * (4 B + 1), B = its main grid (min(512, ceil(full gradient tiles / 4))
+ * blocks whose 4 B waves stride over the ONE sequence of all tensors' full tiles; one more wave per tensor takes the
+ * n mod 1024 elements left).  Pass it to qd_multi_point_grad_f32 unchanged. */
 int64_t qd_multi_dq_plan(QdDiffQuantDesc* host_table, int ntensors, int64_t bucket, int64_t* total_blocks_out);
 int qd_multi_nearest_f32(const QdDiffQuantDesc* table, int ntensors, int64_t total_tiles, int64_t bucket,
                          const float* points, int k, void* stream);

@@ -97,101 +97,261 @@ __global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* __
     }
 }
 
-// backward stage 1: block -> tensor; lane-private LDS columns bins[k][256], plain read-add-write
-__global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc* __restrict__ table, int ntensors, int64_t bucket,
-                                                          int row_shift, int k, float* part /* [blocks][k] */) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];        // [k][256]
-    const int ti = find_owner(table, ntensors, blockIdx.x, true);
-    const QdDiffQuantDesc d = table[ti];
-    const int64_t nblk = (ti + 1 < ntensors ? table[ti + 1].first_block : (int64_t)gridDim.x) - d.first_block;
-    const int64_t bl = blockIdx.x - d.first_block;
-    for (int j = threadIdx.x; j < k * 256; j += 256) lds[j] = 0.0f;
-    __syncthreads();
-    float* col = lds + threadIdx.x;
-    const bool single = d.n <= bucket;                  // one bucket: alpha[0] for every element
-    const float a_single = single ? d.alpha[0] : 0.0f;
-    const int64_t tid = bl * 256 + threadIdx.x, nth = nblk * 256;
-    const bool vec = (((((uintptr_t)d.grad)) & 15) == 0) && ((((uintptr_t)d.idx) & 3) == 0);
-    int64_t done = 0;
-    if (vec) {
-        const int64_t n4 = d.n >> 2;
-        auto add4 = [&](const f4& gv, uint32_t pk, float a) {
-            col[(pk & 255) * 256] += gv.x * a;           // one fp32 multiply each, quant_functions.py:495
-            col[((pk >> 8) & 255) * 256] += gv.y * a;
-            col[((pk >> 16) & 255) * 256] += gv.z * a;
-            col[(pk >> 24) * 256] += gv.w * a;
-        };
-        constexpr int U = 4;                              // float4 in flight per lane (see qd_point_grad_f32's grid note)
-        int64_t i = tid;
-        for (; i + (U - 1) * nth < n4; i += U * nth) {
-            f4 gv[U]; uint32_t pk[U]; float a[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t iu = i + u * nth;
-                gv[u] = ldg_nt((const f4*)d.grad + iu);
-                pk[u] = ldg_nt((const uint32_t*)d.idx + iu);
-                a[u] = single ? a_single : ldg(d.alpha + ((iu << 2) >> row_shift));
-            }
-            __builtin_amdgcn_sched_barrier(0);            // keep the loads together (not sunk to their uses)
-#pragma unroll
-            for (int u = 0; u < U; ++u) add4(gv[u], pk[u], a[u]);
-        }
-        for (; i < n4; i += nth) {
-            const f4 gv = ldg_nt((const f4*)d.grad + i);
-            const uint32_t pk = ldg_nt((const uint32_t*)d.idx + i);
-            add4(gv, pk, single ? a_single : ldg(d.alpha + ((i << 2) >> row_shift)));
-        }
-        done = n4 << 2;
-    }
-    for (int64_t e = done + tid; e < d.n; e += nth)
-        col[(int)d.idx[e] * 256] += d.grad[e] * (single ? a_single : d.alpha[e >> row_shift]);
-    __syncthreads();
-    for (int t = threadIdx.x; t < ((k * 4 + 3) & ~3); t += 256) {        // 4 threads per bin, fixed fold
-        const int j = t >> 2, qd4 = t & 3;
-        float acc = 0.0f;
-        if (j < k)
-            for (int c = 0; c < 64; ++c) acc += lds[j * 256 + qd4 * 64 + ((c + j) & 63)];
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        if (qd4 == 0 && j < k) part[(int64_t)blockIdx.x * k + j] = acc;
-    }
+// ---- backward: grad of the points of every tensor, one launch + one fold --------------------------------------------
+// Work unit: a GRADIENT TILE = 1024 consecutive elements of one tensor (a wave iteration: four 1 KiB rows of gradient, four
+// 256 B rows of uint8 indices).  QdDiffQuantDesc.first_block is the prefix of FULL gradient tiles over the tensors; the
+// tensors' full tiles form ONE sequence 0 ... T - 1, and the main grid strides over it as qd_point_grad_f32's does over its
+// one tensor: wave g of the W = 4 B waves takes tiles g, g + W, g + 2 W, ... -- every wave streams the same number of bytes
+// whatever the tensor sizes are, and the whole grid moves through memory front to back together.  What is left of a tensor
+// after its full tiles (n mod 1024 elements: every bias and batch-norm vector is only that) goes to EXTRA blocks behind the
+// main grid, one wave per tensor: short-lived waves that run beside the sweep instead of inside one of its waves.
+//   round 4: every tensor its own ceil(n / 128 Ki) blocks -- 631 blocks of 65 Ki ... 128 Ki elements on the WRN-16-22 shape
+//            list, 60 tensors swept concurrently: 71.8 us = 72.1 % of the HBM peak; 47.7 us on the 1 M-parameter CIFAR student
+//   round 5 (profiles/r05_ab_k6m.txt): 512 equal blocks, each its own CONTIGUOUS piece of the sequence: 73.5 us -- 512 separate
+//            streaming windows are worse than 60; the wave-strided sequence WITH the partial tiles in it: 74.2 us (on ONE 64 Mi
+//            tensor 54.7 us, the single-tensor kernel's time, against 65.2 us for round 4's) -- 47 of the 60 WRN tensors end
+//            in a partial tile, 43 are nothing else, and each cost one of the 40-tile waves a slow masked tile + two flushes
+// Partial sums: a wave keeps its bins while its tiles stay in one tensor and writes them out -- one row of k floats at
+// [ti][g] -- when they move on to the next one; the extra wave of tensor ti writes row [ti][W].  Which rows exist is a function
+// of the table alone (tensor ti with c full tiles from f0 on: waves (f0 + i) mod W, i < min(c, W); row W iff n mod 1024), so the
+// fold reads exactly the rows that were written and nothing needs zeroing.  Fixed tile -> wave assignment, fixed fold order:
+// deterministic.
+constexpr int kGradTile = 1024;
+
+// T is not an argument of the entry point (the host holds no copy of the device table): the last tensor's prefix + its tiles
+__device__ __forceinline__ int64_t total_grad_tiles(const QdDiffQuantDesc* table, int ntensors) {
+    return table[ntensors - 1].first_block + table[ntensors - 1].n / kGradTile;
 }
 
-// backward stage 2: block (tensor, bin) folds that tensor's partial rows in a fixed order
-__global__ __launch_bounds__(64) void k_multi_point_grad_final(const QdDiffQuantDesc* __restrict__ table, int ntensors,
-                                                               int64_t total_blocks, int k, const float* part,
-                                                               float* grad_points /* [ntensors][k] */) {
+// last tensor whose tile prefix is <= t, for a whole wave at once: every lane looks at one tensor's prefix, a ballot counts
+// (one memory round trip per 64 tensors instead of log2(ntensors) dependent scalar loads before the wave's first tile)
+__device__ __forceinline__ int owner_of_tile(const QdDiffQuantDesc* table, int ntensors, int64_t t, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < ntensors; base += 64) {
+        const int i = base + lane;
+        const bool le = i < ntensors && table[i].first_block <= t;
+        cnt += __popcll(__ballot(le));
+    }
+    return __builtin_amdgcn_readfirstlane(cnt - 1);
+}
+
+// KR > 0: k <= KR bins in registers (compare-select-add); KR == 0: lane-private LDS columns [k][256]
+template <int KR>
+__global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc* __restrict__ table, int ntensors, int B,
+                                                          int64_t bucket, int row_shift, int k, float* part /* [ntensors][4 B + 1][k] */) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // KR == 0: [k][256]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t W = (int64_t)B * 4;
+    float acc[KR > 0 ? KR : 1];
+    float* col = lds + threadIdx.x;                                    // this lane's column; a wave owns columns 64 w ... 64 w + 63
+    auto clear = [&]() {
+        if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] = 0.0f;
+        } else {
+            for (int j = 0; j < k; ++j) col[j * 256] = 0.0f;
+        }
+    };
+    auto add = [&](int id, float m) {
+        if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < (KR > 0 ? KR : 1); ++j) acc[j] += (id == j) ? m : 0.0f;
+        } else {
+            col[id * 256] += m;                                        // private column: plain LDS read-add-write
+        }
+    };
+    auto flush = [&](int ti, int64_t r) {                              // this wave's sums for tensor ti -> row [ti][r], bins cleared
+        float* row = part + ((int64_t)ti * (W + 1) + r) * k;
+        if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < (KR > 0 ? KR : 1); ++j) {
+                // wave_sum() as lane 0 sees it -- (row 0 + row 1) + (row 2 + row 3) -- with the four row sums read as scalars
+                const float rs = row16_sum(acc[j]);
+                const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 0));
+                const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 16));
+                const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 32));
+                const float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs), 48));
+                const float sum = (s0 + s1) + (s2 + s3);
+                if (lane == 0 && j < k) row[j] = sum;
+            }
+        } else {
+            // LDS operations of one wave complete in order; the barriers only pin the compiler.  Lane j folds bin j's 64 columns
+            // of this wave (rotated start: bank-conflict free) in a fixed order.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < k) {
+                const float* base = lds + lane * 256 + 64 * w;
+                float s0 = 0.0f, s1 = 0.0f;
+                for (int c = 0; c < 64; c += 2) { s0 += base[(c + lane) & 63]; s1 += base[(c + 1 + lane) & 63]; }
+                row[lane] = s0 + s1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        clear();
+    };
+    auto scalar_span = [&](const QdDiffQuantDesc& d, int64_t lo, int64_t hi) {        // element by element (a view at an odd offset)
+        const bool single = d.n <= bucket;
+        for (int64_t e = lo + lane; e < hi; e += 64)
+            add((int)d.idx[e], d.grad[e] * d.alpha[single ? 0 : (e >> row_shift)]);
+    };
+
+    if ((int)blockIdx.x >= B) {
+        // ---- the extra waves: what is left of tensor ti after its full tiles
+        const int ti = ((int)blockIdx.x - B) * 4 + w;
+        if (ti >= ntensors) return;
+        const QdDiffQuantDesc d = table[ti];
+        const int64_t rem = d.n % kGradTile;
+        if (rem == 0) return;
+        clear();
+        const int64_t e0 = d.n - rem;
+        const bool single = d.n <= bucket;
+        const bool aligned = ((((uintptr_t)d.grad) & 15) == 0) && ((((uintptr_t)d.idx) & 3) == 0);
+        if (aligned) {
+            // every lane issues its loads up front; the float4 that straddles the end is assembled from scalar loads; elements past
+            // the end add an exact +0 to bin 0 (not 0 x alpha, which is NaN for the alpha = inf of a bucket that holds an infinity)
+            const f4* g4 = (const f4*)(d.grad + e0) + lane;
+            const uint32_t* i4 = (const uint32_t*)(d.idx + e0) + lane;
+            const int64_t left = rem - 4 * lane;                        // elements from this lane's first float4 to the end
+            f4 gv[4]; uint32_t pk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t lu = left - 256 * u;
+                const float* gs = (const float*)(g4 + 64 * u);
+                const uint8_t* is = (const uint8_t*)(i4 + 64 * u);
+                const float al = lu > 0 ? ldg(d.alpha + (single ? 0 : ((e0 + 256 * u + 4 * lane) >> row_shift))) : 0.0f;
+                f4 gq = {0.0f, 0.0f, 0.0f, 0.0f};
+                uint32_t pq = 0;
+                if (lu >= 4) {
+                    gq = ldg_nt(g4 + 64 * u);
+                    pq = ldg_nt(i4 + 64 * u);
+                } else {
+                    if (lu > 0) { gq.x = gs[0]; pq |= (uint32_t)is[0]; }
+                    if (lu > 1) { gq.y = gs[1]; pq |= (uint32_t)is[1] << 8; }
+                    if (lu > 2) { gq.z = gs[2]; pq |= (uint32_t)is[2] << 16; }
+                }
+                gv[u].x = lu > 0 ? gq.x * al : 0.0f; gv[u].y = lu > 1 ? gq.y * al : 0.0f;     // one fp32 multiply each, quant_functions.py:495
+                gv[u].z = lu > 2 ? gq.z * al : 0.0f; gv[u].w = lu > 3 ? gq.w * al : 0.0f;
+                pk[u] = pq;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                add(pk[u] & 255, gv[u].x);
+                add((pk[u] >> 8) & 255, gv[u].y);
+                add((pk[u] >> 16) & 255, gv[u].z);
+                add(pk[u] >> 24, gv[u].w);
+            }
+        } else {
+            scalar_span(d, e0, d.n);
+        }
+        flush(ti, W);
+        return;
+    }
+
+    // ---- the main grid: full tiles only
+    const int64_t T = total_grad_tiles(table, ntensors);
+    const int64_t g = (int64_t)blockIdx.x * 4 + w;                     // a block's waves take four adjacent tiles
+    if (g >= T) return;
+    int ti = owner_of_tile(table, ntensors, g, lane);                  // once per wave
+    clear();
+    QdDiffQuantDesc d = table[ti];
+    int64_t next_first = ti + 1 < ntensors ? table[ti + 1].first_block : T;
+    for (int64_t t = g; t < T; t += W) {
+        if (t >= next_first) {                                          // this wave's tiles have moved on to a later tensor
+            flush(ti, g);
+            do {
+                ++ti;
+                next_first = ti + 1 < ntensors ? table[ti + 1].first_block : T;
+            } while (t >= next_first);
+            d = table[ti];
+        }
+        const int64_t e0 = (t - d.first_block) * kGradTile;
+        const bool aligned = ((((uintptr_t)d.grad) & 15) == 0) && ((((uintptr_t)d.idx) & 3) == 0);
+        if (aligned) {                                                  // four (gradient float4, four indices, alpha) loads up front
+            const f4* g4 = (const f4*)(d.grad + e0) + lane;
+            const uint32_t* i4 = (const uint32_t*)(d.idx + e0) + lane;
+            f4 gv[4]; uint32_t pk[4]; float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gv[u] = ldg_nt(g4 + 64 * u);
+                pk[u] = ldg_nt(i4 + 64 * u);
+                a[u] = ldg(d.alpha + (d.n <= bucket ? 0 : ((e0 + 256 * u + 4 * lane) >> row_shift)));      // n <= bucket: one alpha
+            }
+            __builtin_amdgcn_sched_barrier(0);                          // keep the loads together (not sunk to their uses)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                add(pk[u] & 255, gv[u].x * a[u]);                       // one fp32 multiply each, quant_functions.py:495
+                add((pk[u] >> 8) & 255, gv[u].y * a[u]);
+                add((pk[u] >> 16) & 255, gv[u].z * a[u]);
+                add(pk[u] >> 24, gv[u].w * a[u]);
+            }
+        } else {
+            scalar_span(d, e0, e0 + kGradTile);
+        }
+    }
+    flush(ti, g);
+}
+
+// backward stage 2: block (tensor, bin) folds the rows that tensor's waves wrote, in a fixed order.  Up to 2048 + 1 rows per
+// tensor: 256 threads, eight independent loads in flight each (one dependent load per row and thread was 32 round trips =
+// ~12 us on the WRN shape list, more than the sweep gained).
+__global__ __launch_bounds__(256) void k_multi_point_grad_final(const QdDiffQuantDesc* __restrict__ table, int ntensors,
+                                                                int64_t W, int k, const float* part,
+                                                                float* grad_points /* [ntensors][k] */) {
+    __shared__ double s_w[4];
+    const int64_t T = total_grad_tiles(table, ntensors);
     const int ti = blockIdx.x / k, j = blockIdx.x % k;
-    const int64_t b0 = table[ti].first_block;
-    const int64_t b1 = ti + 1 < ntensors ? table[ti + 1].first_block : total_blocks;
+    const int64_t f0 = table[ti].first_block;
+    const int64_t f1 = ti + 1 < ntensors ? table[ti + 1].first_block : T;
+    const int64_t rows = f1 - f0 < W ? f1 - f0 : W;                     // waves (f0 + i) mod W, i < rows, had a tile of this tensor
+    const float* base = part + (int64_t)ti * (W + 1) * k + j;
+    const int64_t r0 = f0 % W;
+    auto row = [&](int64_t i) { int64_t r = r0 + i; r = r >= W ? r - W : r; return base[r * k]; };
     double acc = 0.0;
-    for (int64_t bI = b0 + threadIdx.x; bI < b1; bI += 64) acc += (double)part[bI * k + j];
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 256 < rows; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = row(i + u * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; i < rows; i += 256) acc += (double)row(i);
+    if (threadIdx.x == 0 && (table[ti].n % kGradTile) != 0) acc += (double)base[W * k];      // the extra wave's row
     acc = wave_sum_d(acc);
-    if (threadIdx.x == 0) grad_points[(int64_t)ti * k + j] = (float)acc;
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) grad_points[(int64_t)ti * k + j] = (float)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 
 }  // namespace
 
 extern "C" {
 
+// blocks of the gradient grid for T tiles: 512 blocks -- 2048 waves x 4 independent 1 KiB streams, the shape that measured
+// best for qd_point_grad_f32 (qd_reductions.hip) -- and no more than one wave per tile
+static int64_t grad_blocks(int64_t T) {
+    int64_t B = (T + 3) / 4;
+    if (B > 512) B = 512;
+    if (B < 1) B = 1;
+    return B;
+}
+
 int64_t qd_multi_dq_plan(QdDiffQuantDesc* host_table, int ntensors, int64_t bucket, int64_t* total_blocks_out) {
     if (!host_table || ntensors <= 0 || bucket <= 0 || !total_blocks_out) return -1;
-    int64_t tiles = 0, blocks = 0;
+    int64_t tiles = 0, gtiles = 0;
     for (int i = 0; i < ntensors; ++i) {
         const int64_t n = host_table[i].n;
         const int64_t row = n < bucket ? (n > 0 ? n : 1) : bucket;
         const int64_t nb = n > 0 ? (n + row - 1) / row : 0;
         host_table[i].first_tile = tiles;
-        host_table[i].first_block = blocks;
+        host_table[i].first_block = gtiles;              // prefix of FULL 1024-element gradient tiles (k_multi_point_grad)
         tiles += (nb + 3) / 4;
-        // ~512 elements per thread: a whole model then runs on a few hundred blocks, each lane streaming four
-        // independent float4 at a time -- the grid shape that measured best for qd_point_grad_f32
-        int64_t nblk = (n + 256 * 4 * 128 - 1) / (256 * 4 * 128);
-        if (nblk < 1) nblk = 1;
-        if (nblk > 512) nblk = 512;
-        blocks += nblk;
+        gtiles += n > 0 ? n / kGradTile : 0;
     }
-    *total_blocks_out = blocks;
+    // partial rows of the gradient sweep: [ntensors][4 B + 1], see k_multi_point_grad
+    *total_blocks_out = (4 * grad_blocks(gtiles) + 1) * ntensors;
     return tiles;
 }
 
@@ -215,16 +375,25 @@ int qd_multi_point_grad_f32(const QdDiffQuantDesc* table, int ntensors, int64_t 
     if (!table || ntensors <= 0 || total_blocks <= 0 || bucket <= 0 || (bucket & (bucket - 1)) || k < 1 || k > kMaxK ||
         !grad_points)
         return QD_ERR_INVALID_ARGUMENT;
+    // total_blocks is what qd_multi_dq_plan wrote: ntensors x (4 B + 1) partial rows
+    const int64_t B = (total_blocks / ntensors - 1) / 4;
+    if (total_blocks != (4 * B + 1) * ntensors || B < 1 || B > 512) return QD_ERR_INVALID_ARGUMENT;
     if (!workspace || (((uintptr_t)workspace) & 15) || workspace_bytes < (size_t)total_blocks * k * sizeof(float))
         return QD_ERR_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
     int row_shift = 0;
     while (((int64_t)1 << row_shift) < bucket) ++row_shift;
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(k_multi_point_grad, dim3((unsigned)total_blocks), dim3(256), (size_t)k * 256 * sizeof(float), st,
-                       table, ntensors, bucket, row_shift, k, part);
-    hipLaunchKernelGGL(k_multi_point_grad_final, dim3((unsigned)(ntensors * k)), dim3(64), 0, st, table, ntensors,
-                       total_blocks, k, part, grad_points);
+    // grid: the B blocks of the sweep over the full tiles + one wave per tensor for what is left after them
+    // (a model without a single full tile has B = 1 and T = 0: that block returns at once)
+    const unsigned grid = (unsigned)(B + (ntensors + 3) / 4);
+    if (k <= 4)
+        hipLaunchKernelGGL((k_multi_point_grad<4>), dim3(grid), dim3(256), 0, st, table, ntensors, (int)B, bucket, row_shift, k, part);
+    else
+        hipLaunchKernelGGL((k_multi_point_grad<0>), dim3(grid), dim3(256), (size_t)k * 256 * sizeof(float), st, table, ntensors, (int)B,
+                           bucket, row_shift, k, part);
+    hipLaunchKernelGGL(k_multi_point_grad_final, dim3((unsigned)(ntensors * k)), dim3(256), 0, st, table, ntensors, 4 * B, k, part,
+                       grad_points);
     return (int)hipGetLastError();
 }
 

@@ -87,6 +87,55 @@ def test_multi_plan_host(lib):
     assert tiles == 785
 
 
+def test_multi_dq_plan_host_and_the_partial_row_layout(lib):
+    """qd_multi_dq_plan: first_tile = prefix of 4-bucket forward tiles, first_block = prefix of FULL 1024-element gradient
+    tiles, total_blocks = ntensors x (W + 1) partial rows with W = 4 B waves, B = min(512, ceil(T / 4)).  And the layout claim
+    the backward kernels rest on (csrc/qd_multi_dq.hip): wave g takes full tiles g, g + W, ...; the fold of tensor ti (c full
+    tiles from f0 on) reads rows (f0 + i) mod W, i < min(c, W) -- exactly the waves that had a tile of it, each once -- plus
+    row W iff n mod 1024 (the extra wave's).  Modelled here in Python on the config shape lists and on adversarial ones (empty
+    tensors, tensors below one tile, a single huge tensor)."""
+    import ctypes
+    import numpy as np
+    from harness import kernel_bench
+
+    def plan(ns, bucket=256):
+        T = (_lib.QdDiffQuantDesc * len(ns))()
+        for i, n in enumerate(ns):
+            T[i].n = n
+        blocks = ctypes.c_int64(0)
+        tiles = lib.qd_multi_dq_plan(T, len(ns), bucket, ctypes.byref(blocks))
+        return tiles, blocks.value, [T[i].first_tile for i in range(len(ns))], [T[i].first_block for i in range(len(ns))]
+
+    tiles, rows, ft, fb = plan([800000, 10, 0, 1025, 5000])
+    assert ft == [0, 782, 783, 783, 785] and tiles == 790
+    assert fb == [0, 781, 781, 781, 782]                      # n // 1024: 781, 0, 0, 1, 4
+    assert rows == 5 * (4 * min(512, -(-786 // 4)) + 1)
+    assert plan([0, 0])[1] == 2 * (4 * 1 + 1)                    # nothing to do: one block, which returns at once
+
+    rng = np.random.RandomState(0)
+    cases = [[int(np.prod(s)) for s in kernel_bench.model_shapes('wrn')], [int(np.prod(s)) for s in kernel_bench.model_shapes('student')],
+             [1 << 26], [1, 1, 1, 1, 1, 1, 1, 1, 1], [0, 5, 0, 0, 7000, 0, 3, 0], [1024] * 40 + [0] + [1025] * 3,
+             [int(x) for x in rng.randint(0, 300000, 200)], [int(x) for x in rng.randint(1, 3000, 64)], [3 << 20, 0, 1, 5 << 20]]
+    for ns in cases:
+        _tiles, rows, _ft, fb = plan(ns)
+        nt = len(ns)
+        T = fb[-1] + ns[-1] // 1024
+        assert T == sum(n // 1024 for n in ns) and rows % nt == 0 and (rows // nt - 1) % 4 == 0
+        W = rows // nt - 1
+        assert 4 <= W <= 2048 and W == 4 * max(1, min(512, -(-T // 4)))
+        tiles_t = np.arange(T)
+        owner = np.searchsorted(np.asarray(fb + [T]), tiles_t, side='right') - 1         # last tensor with prefix <= t ...
+        wave = tiles_t % W
+        for ti in range(nt):
+            touched = sorted(set(wave[owner == ti].tolist())) if T else []
+            c = ns[ti] // 1024
+            if c == 0:                                            # ... which never is a tensor without a full tile
+                assert not touched
+                continue
+            read = [(fb[ti] + i) % W for i in range(min(c, W))]
+            assert len(set(read)) == len(read) and sorted(read) == touched
+
+
 def test_kernels_are_gfx950_only(lib):
     """The fat binary carries exactly one device target: gfx950 (no multi-arch, no fallbacks)."""
     blob = open(_lib.LIB_PATH, 'rb').read()

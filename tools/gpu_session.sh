@@ -21,6 +21,7 @@
 #   coverage   tools/launch_coverage.py --run: the GPU suite under rocprofv3 --kernel-trace --stats, shipped kernels never launched
 #   dispatch   tools/dispatch_map.py --trace: call geometry -> kernel map
 #   driver     the driver's exact command (python3 bench.py --gpus 1 --steps 20 --warmup 5), output numbered by DRIVER_TAG (soak: one per lease)
+#   abk6m      tools/ab_k6m.py: the multi-tensor point-gradient sweep, this build against build/libqd_hip_prev.so
 #   capture    tests/test_hip_capture_watchdog.py, then the round-4 configuration on purpose (global-mode capture, collectives in flight)
 set +e
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -103,6 +104,15 @@ PYEOF
              grep -m3 "capturing\|CAPTURE_OK\|terminate" gpurun_out/capture_global_mode.log | cut -c1-300
              timeout 600 python tests/capture_worker.py --mode global --settle 0.35 --iters 20 > gpurun_out/capture_global_mode_settled.log 2>&1; echo "global-mode capture after quiescing: rc=$?"
              grep -m3 "capturing\|CAPTURE_OK\|terminate" gpurun_out/capture_global_mode_settled.log | cut -c1-300 ;;
+    abk6m)   timeout 900 python tools/ab_k6m.py ${ABK6M_ARGS:-4 16 64} 2>&1 | grep -v amdgpu.ids > gpurun_out/ab_k6m.txt; cat gpurun_out/ab_k6m.txt
+             # per-kernel durations (sweep and fold separately), per shape list
+             for m in wrn one64Mi; do
+               rm -rf gpurun_out/abk6m_stats
+               (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abk6m_stats -o ab -- python $R/tools/ab_k6m.py 4 --models=$m > /dev/null 2> $R/gpurun_out/abk6m_prof.err); echo "abk6m rocprof $m rc=$?"
+               find gpurun_out/abk6m_stats -name '*kernel_stats.csv' -exec cp {} gpurun_out/ab_k6m_kernel_stats_$m.csv \;
+               grep "point_grad" gpurun_out/ab_k6m_kernel_stats_$m.csv | cut -c1-200
+             done
+             rm -rf gpurun_out/abk6m_stats ;;
     *)       echo "unknown step $step" ;;
   esac
 done
