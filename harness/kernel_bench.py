@@ -159,6 +159,10 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         add('K4 nonUniform k=%d b256 (int64 idx)' % k, 'k_bucket_vec<2,16,4,1>',
             lambda i, pts=pts: keep(i, quantization.nonUniformQuantization(xs[i % R], pts, bucket_size=256)[:2]), 16, N,
             note='q and the int64 indices of the last 4 calls stay alive; 177-201 us box to box with one binary (profiles/r04_ab_idx_stores.txt)')
+        if k == 4:
+            add('K4 nonUniform k=4 b256 (uint8 idx: index_dtype opt-in)', 'k_bucket_vec<2,16,4,1>',
+                lambda i, pts=pts: keep(i, quantization.nonUniformQuantization(xs[i % R], pts, bucket_size=256, index_dtype=torch.uint8)[:2]), 9, N,
+                note="the same call with one-byte indices: 9 instead of 16 B/element")
         fns = [quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=xs[j]) for j in range(3)]
         add('K5 diff-quant forward k=%d (u resident, u8 idx)' % k, 'k_nearest_prescaled_stream<false>',
             lambda i, pts=pts, fns=fns: fns[i % 3].forward(None, pts), 9, N)

@@ -1,8 +1,15 @@
-"""ctypes binding of libqd_hip.so (C ABI: include/qd_hip.h).
+"""ctypes binding of libqd_hip.so (C ABI: include/qd_hip.h), and of libqd_host.so for CPU tensors.
 
 PyTorch is used only for device memory and the current HIP stream; every kernel is launched
 through the C ABI with raw device pointers.  Loading fails loudly when the library has not been
 built -- there is no fallback implementation.
+
+One library per device: a tensor on a HIP device goes to libqd_hip.so and nowhere else (a missing
+libqd_hip.so is an error, whatever else is installed); a CPU tensor goes to libqd_host.so
+(csrc/host/qd_host.cpp: the per-call entry points of the same header for host pointers -- the
+reference's functions accept CPU tensors, quantization/quant_functions.py:186,254,283-284).  The
+choice is made from the tensor's device by lib_for(); nothing is ever computed on another
+device than the one the caller's tensor lives on.
 """
 import ctypes
 import os
@@ -10,6 +17,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libqd_hip.so')
+HOST_LIB_PATH = os.path.join(_HERE, 'libqd_host.so')      # the same entry points for CPU tensors (csrc/host/qd_host.cpp)
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 
@@ -116,6 +124,46 @@ def load():
     return _lib
 
 
+# the entry points libqd_host.so implements (the per-call functions; multi-tensor, codec, order statistics and the
+# 'absmax' / 'absnorm' scalings exist for device tensors only)
+HOST_SYMBOLS = ('qd_abi_version', 'qd_target_arch', 'qd_error_string', 'qd_workspace_bytes', 'qd_num_buckets', 'qd_padded_length',
+                'qd_mean_f32', 'qd_uniform_f32', 'qd_scale_down_f32', 'qd_inv_scale_f32', 'qd_bucket_argminmax_f32',
+                'qd_nearest_point_f32', 'qd_point_grad_f32', 'qd_ste_bucket_backward_f32', 'qd_clamp_f32', 'qd_truncated_ste_f32')
+_host = None
+
+
+def host():
+    """Load libqd_host.so (once): the library CPU tensors are computed by.  Raises QdLibraryMissing if it has not been built."""
+    global _host
+    if _host is not None:
+        return _host
+    with _lock:
+        if _host is not None:
+            return _host
+        if not os.path.exists(HOST_LIB_PATH):
+            raise QdLibraryMissing(
+                'quantized_distillation_amd: %s is missing. Build it first: '
+                'python -c "import __graft_entry__ as g; g.build()" (needs g++ with OpenMP).' % HOST_LIB_PATH)
+        lib = ctypes.CDLL(HOST_LIB_PATH)
+        for name in HOST_SYMBOLS:
+            res, args = SIGNATURES[name]
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        lib.qd_host_max_threads.restype = c_int
+        lib.qd_host_max_threads.argtypes = []
+        if lib.qd_abi_version() != ABI_VERSION:
+            raise RuntimeError('libqd_host.so has ABI version %d, this binding is written for %d: rebuild it '
+                               '(python -c "import __graft_entry__ as g; g.build()")' % (lib.qd_abi_version(), ABI_VERSION))
+        _host = lib
+    return _host
+
+
+def lib_for(t):
+    """The library that computes on `t`'s device: libqd_hip.so for a HIP tensor, libqd_host.so for a CPU tensor."""
+    return load() if t.is_cuda else host()
+
+
 _glue = None
 GLUE_PATH = os.path.join(_HERE, '_qd_glue.so')
 
@@ -142,6 +190,11 @@ def glue():
 def mark_written(tensors):
     """A kernel launched through ctypes wrote over `tensors` (one tensor or a sequence): bump their version counters, as an
     in-place torch op would have -- ScalingFunction's lazy arg indices and autograd's saved-tensor check rely on it."""
+    import torch
+    first = tensors if isinstance(tensors, torch.Tensor) else (tensors[0] if len(tensors) else None)
+    if first is not None and not first.is_cuda:
+        torch.autograd.graph.increment_version(tensors if isinstance(tensors, torch.Tensor) else tuple(tensors))
+        return
     glue().mark_written(tensors)
 
 
@@ -185,12 +238,45 @@ def on_other_device(t):
     return t.is_cuda and t.device.index is not None and t.device.index != torch.cuda.current_device()
 
 
+_host_scratch = None
+
+
+def workspace_for(t):
+    """Scratch buffer for a call on `t`'s device: the per-stream device workspace, or (CPU) a token buffer -- libqd_host.so
+    needs none."""
+    global _host_scratch
+    if t.is_cuda:
+        return workspace(t.device)
+    if _host_scratch is None:
+        import torch
+        _host_scratch = torch.empty(16, dtype=torch.uint8)
+    return _host_scratch
+
+
+def stream_for(t):
+    """hipStream_t of the current stream on `t`'s device, None for a CPU tensor (the host call is complete when it returns)."""
+    return stream_ptr(t.device) if t.is_cuda else None
+
+
+def require_f32(t, what='tensor'):
+    """A float32 tensor on a HIP device or on the CPU (the entry points that exist in both libraries)."""
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %r' % (what, type(t)))
+    if not (t.is_cuda or t.device.type == 'cpu'):
+        raise RuntimeError('quantized_distillation_amd: %s must live on a HIP device or on the CPU (got %s)' % (what, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32 (the reference path is fp32-only), got %s' % (what, t.dtype))
+
+
 def require_device_f32(t, what='tensor'):
+    """A float32 tensor on a HIP device: the entry points that exist for device tensors only (multi-tensor launches, the
+    packed codec, device histograms and order statistics)."""
     import torch
     if not isinstance(t, torch.Tensor):
         raise TypeError('%s must be a torch.Tensor, got %r' % (what, type(t)))
     if not t.is_cuda:
         raise RuntimeError('quantized_distillation_amd: %s must live on a HIP device (got %s); '
-                           'this package has no CPU path' % (what, t.device))
+                           'this entry point has no CPU path' % (what, t.device))
     if t.dtype != torch.float32:
         raise TypeError('%s must be float32 (the reference path is fp32-only), got %s' % (what, t.dtype))

@@ -135,6 +135,31 @@ def build_glue(force=False, verbose=False):
     return out
 
 
+HOST_FLAGS = ['-O2', '-std=c++17', '-fPIC', '-shared', '-fopenmp',
+              '-ffp-contract=off', '-fno-fast-math',     # as the device build: every fp32 op rounded separately, no reassociation
+              '-fvisibility=hidden',                      # only the extern "C" entry points leave the library ...
+              '-Wl,-Bsymbolic-functions']                 # ... and its own calls to them never resolve into libqd_hip.so (same names)
+
+
+def build_host(force=False, verbose=False):
+    """libqd_host.so: the per-call entry points of include/qd_hip.h for CPU tensors (csrc/host/qd_host.cpp), g++ + OpenMP."""
+    src = os.path.join(_lib.CSRC, 'host', 'qd_host.cpp')
+    out = _lib.HOST_LIB_PATH
+    deps = [src, os.path.join(_lib.INCLUDE, 'qd_hip.h'), os.path.abspath(__file__)]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cxx = shutil.which('g++') or shutil.which('c++')
+    if cxx is None:
+        raise RuntimeError('g++ not found')
+    cmd = [cxx] + HOST_FLAGS + ['-I', _lib.INCLUDE, src, '-o', _tmp(out)]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(_tmp(out), out)
+    return out
+
+
 if __name__ == '__main__':
     print(build_extension(force=True, verbose=True))
     print(build_glue(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -2,8 +2,8 @@
 cited as `ref:`).  These run off the per-step path: bucket reshaping for callers that want the
 view, the percentile initialisation of the quantization points, the bit-allocation heuristic
 and the Huffman size accounting.  The per-tensor work they need (scaling, assignment) goes
-through the HIP kernels; what remains on the host is what the reference also does on the host
-(np.percentile, a heap, a dict of frequencies).
+through the HIP kernels (libqd_host.so for CPU tensors); what remains on the host is what the
+reference also does on the host (np.percentile, a heap, a dict of frequencies).
 """
 import math  # noqa: F401  (kept for API parity with the reference module namespace)
 from collections import defaultdict
@@ -141,12 +141,15 @@ def order_statistics(values, ranks):
     2 * 32 distinct ranks (num_points > 32): one device sort and a gather instead."""
     from .. import _lib
     flat = values.reshape(-1)
-    if flat.dtype != torch.float32 or not flat.is_cuda:
-        raise TypeError('order_statistics needs a float32 tensor on the GPU, got %s on %s' % (flat.dtype, flat.device))
+    if flat.dtype != torch.float32:
+        raise TypeError('order_statistics needs a float32 tensor, got %s on %s' % (flat.dtype, flat.device))
     ranks = np.asarray(ranks, dtype=np.int64)
     n = flat.numel()
     if ranks.size and (ranks.min() < 0 or ranks.max() >= n):
         raise IndexError('rank out of range for %d elements' % n)
+    if not flat.is_cuda:                   # a CPU tensor: the selection on the host (np.partition places exactly the asked ranks)
+        wanted = np.unique(ranks)
+        return np.partition(flat.numpy(), wanted)[ranks] if wanted.size else np.empty(ranks.shape, dtype=np.float32)
     distinct, inverse = np.unique(ranks, return_inverse=True)
     lib = _lib.load()
     chunk = 32                                                          # QD_ORDER_STATS_MAX_RANKS

@@ -8,7 +8,10 @@ can call it unchanged.  What differs is *how* it runs: each call is one (at most
 kernel launches through the C ABI of include/qd_hip.h instead of ~12 unfused torch ops, there
 is no host synchronisation and no device<->host round trip anywhere on the per-step path.
 
-Tensors must be float32 and live on a HIP device; there is no CPU path in this package.
+Tensors must be float32.  A tensor on a HIP device is computed by libqd_hip.so; a CPU tensor -- the reference's
+functions accept those too (ref: :186,254,283-284) -- by libqd_host.so, the same entry points for host pointers
+(csrc/host/qd_host.cpp), with results on the CPU.  The tensor's device decides, nothing else does: there is no fallback
+from one to the other (_lib.lib_for).
 """
 import numbers
 
@@ -19,7 +22,7 @@ from .. import _lib
 _STOCHASTIC_CALLS = [0]
 
 
-def next_stochastic_seed(peek=False):
+def next_stochastic_seed(peek=False, host=False):
     """Seed of the next stochastic-rounding launch.  The reference draws torch.rand on the host
     (ref: :185-186); here the draws come from an in-kernel counter-based generator keyed by this
     seed and the element index.  The seed is derived from the CURRENT DEVICE's default generator
@@ -28,7 +31,8 @@ def next_stochastic_seed(peek=False):
     calls = _STOCHASTIC_CALLS[0] + 1
     if not peek:
         _STOCHASTIC_CALLS[0] = calls
-    return (torch.cuda.initial_seed() * 0x9E3779B97F4A7C15 + calls) & 0xFFFFFFFFFFFFFFFF
+    base = torch.initial_seed() if host else torch.cuda.initial_seed()       # (CPU tensors: the CPU generator's seed)
+    return (base * 0x9E3779B97F4A7C15 + calls) & 0xFFFFFFFFFFFFFFFF
 
 
 def _bucket_arg(bucket_size):
@@ -186,7 +190,7 @@ class ScalingFunction(object):
 
     def _begin(self, tensor):
         """Record sizes, compute the mean if requested; returns (flat contiguous tensor, n, nb, row)."""
-        _lib.require_device_f32(tensor)
+        _lib.require_f32(tensor)
         if not tensor.is_contiguous():
             if self.modify_in_place:
                 raise ValueError('modify_in_place=True needs a contiguous tensor')
@@ -198,9 +202,9 @@ class ScalingFunction(object):
         if self.subtract_mean:
             self._mean_buf = torch.empty(1, dtype=torch.float32, device=tensor.device)
             if n > 0:
-                ws = _lib.workspace(tensor.device)
-                _lib.check(_lib.load().qd_mean_f32(tensor.data_ptr(), n, self._mean_buf.data_ptr(),
-                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                ws = _lib.workspace_for(tensor)
+                _lib.check(_lib.lib_for(tensor).qd_mean_f32(tensor.data_ptr(), n, self._mean_buf.data_ptr(),
+                                                            ws.data_ptr(), ws.numel(), _lib.stream_for(tensor)))
             self.mean_tensor = self._mean_buf.view(())                               # 0-dim, ref: :67
         else:
             self._mean_buf = None
@@ -240,10 +244,10 @@ class ScalingFunction(object):
         out = torch.empty(2, nb, dtype=torch.int64, device=t.device)
         clamp, me = self._clamp_args()
         if n > 0:
-            ws = _lib.workspace(t.device)
-            _lib.check(_lib.load().qd_bucket_argminmax_f32(
+            ws = _lib.workspace_for(t)
+            _lib.check(_lib.lib_for(t).qd_bucket_argminmax_f32(
                 t.data_ptr(), n, _bucket_arg(self.bucket_size), _ptr(self._mean_buf), clamp, me,
-                out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_for(t)))
         shape = (1,) if self.bucket_size is None else (nb, 1)
         self._idx_min_rows = out[0].view(*shape)
         self._idx_max_rows = out[1].view(*shape)
@@ -289,16 +293,17 @@ class ScalingFunction(object):
         ab = self._alloc_alpha_beta(nb, tensor.device)
         clamp, me = self._clamp_args()
         if n > 0:
-            ws = _lib.workspace(tensor.device)
-            _lib.check(_lib.load().qd_scale_down_f32(
+            ws = _lib.workspace_for(tensor)
+            _lib.check(_lib.lib_for(tensor).qd_scale_down_f32(
                 tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(self.bucket_size), ab[0].data_ptr(),
-                ab[1].data_ptr(), _ptr(self._mean_buf), clamp, me, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                ab[1].data_ptr(), _ptr(self._mean_buf), clamp, me, ws.data_ptr(), ws.numel(), _lib.stream_for(tensor)))
             if in_place:
                 _lib.mark_written(tensor)          # the kernel wrote over the input through its raw pointer
         return out.view(self.expected_tensor_size)
 
     def _scale_down_abs(self, tensor, n, nb, padded):
         """sign + magnitude scaling (intended math of ref: :109-127): u = |x| / norm_b."""
+        _abs_needs_device(tensor)
         dev = tensor.device
         u = torch.empty(padded, dtype=torch.float32, device=dev)
         sign = torch.empty(padded, dtype=torch.float32, device=dev)
@@ -318,7 +323,7 @@ class ScalingFunction(object):
         if isinstance(tensor, torch.Tensor) and _lib.on_other_device(tensor):
             with torch.cuda.device(tensor.device):
                 return self.inv_scale_down(tensor)
-        _lib.require_device_f32(tensor)
+        _lib.require_f32(tensor)
         if tensor.size() != self.expected_tensor_size:                               # ref: :138-139
             raise ValueError('The tensor passed has not the expected size.')
         if not tensor.is_contiguous():
@@ -327,6 +332,7 @@ class ScalingFunction(object):
         if self._abs_kind() is not None:                                             # ref: :144-146
             if self.tensor_sign is None:
                 raise ValueError('inv_scale_down needs the signs recorded by scale_down')
+            _abs_needs_device(tensor)
             out = torch.empty(n, dtype=torch.float32, device=tensor.device)
             if n > 0:
                 _lib.check(_lib.load().qd_inv_scale_abs_f32(
@@ -336,12 +342,43 @@ class ScalingFunction(object):
         out = tensor.view(-1)[0:n] if self.modify_in_place else torch.empty(n, dtype=torch.float32,
                                                                           device=tensor.device)
         if n > 0:
-            _lib.check(_lib.load().qd_inv_scale_f32(
+            _lib.check(_lib.lib_for(tensor).qd_inv_scale_f32(
                 tensor.data_ptr(), out.data_ptr(), n, _bucket_arg(self.bucket_size), self.alpha.data_ptr(),
-                self.beta.data_ptr(), _ptr(self._mean_buf), _lib.stream_ptr()))
+                self.beta.data_ptr(), _ptr(self._mean_buf), _lib.stream_for(tensor)))
             if self.modify_in_place:
                 _lib.mark_written(tensor)
         return out.view(self.original_tensor_size)
+
+
+def _abs_needs_device(tensor):
+    if not tensor.is_cuda:
+        raise NotImplementedError("'absmax' / 'absnorm' scaling is implemented for tensors on a HIP device only (the reference's "
+                                  "own code for the two raises on every torch version, ref: :109-127)")
+
+
+def _uniform_host(tensor, s, type_of_scaling, stochastic_rounding, max_element, subtract_mean, bucket_size, modify_in_place):
+    """uniformQuantization of a CPU tensor: the same single call into the C ABI (qd_uniform_f32: per-bucket min/max, alpha/beta,
+    scale, round, rescale in one pass), served by libqd_host.so.  ref: :155-194."""
+    sf = ScalingFunction(type_of_scaling, max_element, subtract_mean, bucket_size, True)    # validates as the reference, :22-33,166-167
+    if int(s) != s or s < 2:
+        raise ValueError('s must be an integer >= 2')
+    if sf.type_scaling != 'linear':
+        _abs_needs_device(tensor)
+    sf.modify_in_place = modify_in_place                   # governs _begin's contiguity rule
+    x, n, nb, row = sf._begin(tensor)                      # sizes, the mean if asked for
+    sf.modify_in_place = True
+    sf._note_arg_source(x, overwritten=bool(modify_in_place))      # the lazy arg indices: now, if x is about to be overwritten
+    q = x if modify_in_place else torch.empty_like(x)
+    ab = sf._alloc_alpha_beta(nb, x.device)
+    clamp, me = sf._clamp_args()
+    if n > 0:
+        _lib.check(_lib.host().qd_uniform_f32(
+            x.data_ptr(), q.data_ptr(), n, _bucket_arg(bucket_size), int(s), ab[0].data_ptr(), ab[1].data_ptr(), None,
+            _ptr(sf._mean_buf), clamp, me, 1 if stochastic_rounding else 0,
+            next_stochastic_seed(host=True) if stochastic_rounding else 0, None, 0, None))
+        if modify_in_place:
+            _lib.mark_written(x)
+    return q.view(sf.original_tensor_size), sf
 
 
 _glue_uniform = None
@@ -366,6 +403,9 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     place; ref: conv_forward_model.py:216-221) takes a path with the argument checks inlined --
     this function is called once per parameter tensor per step."""
     global _glue_uniform, _glue_uniform_common
+    if type(tensor) is torch.Tensor and not tensor.is_cuda:          # a CPU tensor: libqd_host.so (the tensor's device decides)
+        return _uniform_host(tensor, s, type_of_scaling, stochastic_rounding, max_element, subtract_mean, bucket_size,
+                             modify_in_place)
     if _glue_uniform is None:
         g = _lib.glue()
         g.register(ScalingFunction)
@@ -469,7 +509,7 @@ class SearchSorted:
     therefore only keeps `u` (fp32, device, unpadded order) resident between steps."""
 
     def __init__(self, tensor, use_k_optimization=True):
-        _lib.require_device_f32(tensor, 'SearchSorted tensor')
+        _lib.require_f32(tensor, 'SearchSorted tensor')
         self.scaled_tensor = tensor.contiguous().view(-1)
         self.use_k_optimization = use_k_optimization
 
@@ -481,16 +521,16 @@ class SearchSorted:
         idx = torch.empty(n, dtype=torch.int64, device=self.scaled_tensor.device)
         one = torch.ones(1, dtype=torch.float32, device=pts.device)
         zero = torch.zeros(1, dtype=torch.float32, device=pts.device)
-        ws = _lib.workspace(pts.device)
+        ws = _lib.workspace_for(pts)
         if n > 0:
             # indices only (q = NULL): 4 B read + 8 B written per element; the kernel wants n >= 4 and a 16-byte aligned base,
             # the few-element / offset-view case writes its values into a throw-away buffer instead
             only = n >= 4 and self.scaled_tensor.data_ptr() % 16 == 0
             scratch = None if only else torch.empty(n, dtype=torch.float32, device=self.scaled_tensor.device)
-            _lib.check(_lib.load().qd_nearest_point_f32(
+            _lib.check(_lib.lib_for(self.scaled_tensor).qd_nearest_point_f32(
                 self.scaled_tensor.data_ptr(), 1, pts.data_ptr(), pts.numel(), 1, None if only else scratch.data_ptr(),
                 idx.data_ptr(), 8, n, 0, one.data_ptr(), zero.data_ptr(), None, 0, 0.0,
-                ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                ws.data_ptr(), ws.numel(), _lib.stream_for(self.scaled_tensor)))
         return idx
 
 
@@ -509,6 +549,16 @@ def _points_on(points, device):
 def _nearest(x, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mean_buf, clamp, me, idx_bytes, in_place=False):
     """(q [n], idx [n]) -- one K4/K5 launch through the native binding (allocation + stream + launch).  in_place: q is
     written over x (every kernel of the family loads a bucket before it stores it)."""
+    if not x.is_cuda:                                   # a CPU tensor: the same entry point of libqd_host.so
+        q = x.view(-1)[0:n] if in_place else torch.empty(n, dtype=torch.float32)
+        idx = torch.empty(n, dtype=torch.int64 if idx_bytes == 8 else torch.uint8)
+        if n > 0:
+            _lib.check(_lib.host().qd_nearest_point_f32(
+                x.data_ptr(), 1 if prescaled else 0, points.data_ptr(), points.numel(), assign_mode, q.data_ptr(), idx.data_ptr(),
+                idx_bytes, n, bucket_size or 0, alpha.data_ptr(), beta.data_ptr(), _ptr(mean_buf), clamp, me, None, 0, None))
+            if in_place:
+                _lib.mark_written(x)
+        return q, idx
     return _lib.glue().nearest(x, prescaled, points, assign_mode, n, bucket_size or 0, alpha, beta, mean_buf,
                                clamp, me, idx_bytes, in_place)
 
@@ -516,10 +566,14 @@ def _nearest(x, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mea
 def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
                            subtract_mean=False, modify_in_place=False, bucket_size=None,
                            pre_processed_values=False, search_sorted_obj=None, scaling_function=None,
-                           tensors_info=None):
+                           tensors_info=None, index_dtype=torch.int64):
     """Quantize every element to the nearest of the (sorted, in [0,1]) quantization points after
     per-bucket linear scaling.  Returns (quantized, indices int64 of the same shape,
     ScalingFunction).  ref: :196-290.
+
+    index_dtype (an extension; the default is the reference's LongTensor, :288-289): torch.uint8 returns the same indices
+    one byte each -- 9 instead of 16 bytes of HBM traffic per element, 12 of the 16 being the int64 store -- for at most 256
+    points; `indices.long()` is then exactly what the default returns.
 
     Plain path: one fused kernel (K4: scale, nearest point by the distance rule of :267-273,
     gather, rescale).  Pre-processed path (`pre_processed_values=True`, the per-step call of
@@ -531,7 +585,12 @@ def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
         with torch.cuda.device(_where.device):
             return nonUniformQuantization(tensor, listQuantizationPoints, max_element, subtract_mean, modify_in_place,
                                           bucket_size, pre_processed_values, search_sorted_obj, scaling_function,
-                                          tensors_info)
+                                          tensors_info, index_dtype)
+    if index_dtype not in (torch.int64, torch.uint8):
+        raise ValueError('index_dtype must be torch.int64 (the reference\'s) or torch.uint8')
+    if index_dtype is torch.uint8 and len(listQuantizationPoints) > 256:
+        raise ValueError('uint8 indices address at most 256 quantization points')
+    idx_bytes = 8 if index_dtype is torch.int64 else 1
     if pre_processed_values is True and (search_sorted_obj is None or scaling_function is None
                                          or tensors_info is None):                  # ref: :230-231
         raise ValueError('If values are preprocessed, all pre processed arguments need to be passed')
@@ -551,14 +610,14 @@ def nonUniformQuantization(tensor, listQuantizationPoints, max_element=False,
         sf._alloc_alpha_beta(nb, tensor.device)
         clamp, me = sf._clamp_args()
         q, idx = _nearest(tensor, False, points, 0, n, bucket_size, sf.alpha, sf.beta, sf._mean_buf,
-                          clamp, me, 8, in_place=bool(modify_in_place))          # in place: the kernel writes over the input
+                          clamp, me, idx_bytes, in_place=bool(modify_in_place))  # in place: the kernel writes over the input
         return q.view(sf.original_tensor_size), idx.view(sf.original_tensor_size), sf
 
     sf = scaling_function
     u = search_sorted_obj.scaled_tensor
     n = sf.original_tensor_length
     points = _points_on(listQuantizationPoints, u.device)
-    q, idx = _nearest(u, True, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf, 0, 0.0, 8)
+    q, idx = _nearest(u, True, points, 1, n, sf.bucket_size, sf.alpha, sf.beta, sf._mean_buf, 0, 0.0, idx_bytes)
     return q.view(sf.original_tensor_size), idx.view(sf.original_tensor_size), sf
 
 
@@ -601,7 +660,9 @@ class uniformQuantization_variable(object):
         if self.saved_for_backward is None:                                          # ref: :336-337
             raise ValueError('Need to have called .forward() to be able to call .backward()')
         x = self.saved_for_backward['input']
-        _lib.require_device_f32(grad_output, 'grad_output')
+        _lib.require_f32(grad_output, 'grad_output')
+        if grad_output.device != x.device:
+            raise ValueError('grad_output must live on the device of the input of forward()')
         if _lib.on_other_device(grad_output):
             with torch.cuda.device(grad_output.device):
                 return self.backward(grad_output, tie_mode)
@@ -610,9 +671,10 @@ class uniformQuantization_variable(object):
             raise ValueError('grad_output must have as many elements as the input of forward()')
         out = torch.empty_like(g)
         if x.numel() > 0:
-            _lib.check(_lib.load().qd_ste_bucket_backward_f32(
+            x = x.contiguous()
+            _lib.check(_lib.lib_for(x).qd_ste_bucket_backward_f32(
                 x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel(), int(self.bucket_size), int(self.s),
-                0 if tie_mode == 'reference' else 1, _lib.stream_ptr()))
+                0 if tie_mode == 'reference' else 1, _lib.stream_for(x)))
         self.saved_for_backward = None                                               # ref: :404-405
         return out.view(x.size())
 
@@ -699,13 +761,23 @@ class nonUniformQuantization_variable(object):
         """Returns (grad wrt the input = grad_output unchanged, grad wrt the points).  ref: :471-506."""
         if self.savedForBackward is None:                                             # ref: :478-479
             raise ValueError('Need savedIndices to be able to call backward()')
-        _lib.require_device_f32(grad_output, 'grad_output')
+        _lib.require_f32(grad_output, 'grad_output')
         if _lib.on_other_device(grad_output):
             with torch.cuda.device(grad_output.device):
                 return self.backward(grad_output)
         idx = self.savedForBackward.raw_indices()
         k = self.savedForBackward['numPoints']
         alpha = self.savedForBackward['scalingFactor']
+        if not grad_output.is_cuda:                         # CPU tensors: the same entry point of libqd_host.so
+            g = grad_output.contiguous()
+            if idx.device != g.device or idx.numel() != g.numel():
+                raise ValueError('grad_output must match the quantized tensor in size and device')
+            grad_points = torch.empty(int(k), dtype=torch.float32)
+            _lib.check(_lib.host().qd_point_grad_f32(
+                g.data_ptr(), idx.data_ptr(), 8 if idx.dtype == torch.int64 else 1, alpha.data_ptr(), g.numel(),
+                self.bucket_size or 0, int(k), grad_points.data_ptr(), None, 0, None))
+            self.savedIndices = None                                                  # ref: :505
+            return grad_output, grad_points
         grad_points = _lib.glue().point_grad(grad_output, idx, alpha, self.bucket_size or 0, int(k))
         self.savedIndices = None                                                      # ref: :505
         return grad_output, grad_points

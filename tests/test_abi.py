@@ -145,7 +145,8 @@ def test_kernels_are_gfx950_only(lib):
 
 def test_native_glue_loads_and_fails_loudly_on_cpu_tensors():
     """_qd_glue.so (csrc/qd_torch_glue.cpp) is the per-call binding the Python API uses: it must load, agree with
-    libqd_hip.so on the ABI version, and refuse CPU tensors -- there is no CPU path and no ctypes fallback for it."""
+    libqd_hip.so on the ABI version, and refuse CPU tensors -- it is the DEVICE library's binding; CPU tensors never reach it
+    (the public API sends them to libqd_host.so by the tensor's device: tests/test_host_parity.py)."""
     import pytest
     import torch
     from quantized_distillation_amd import _lib
@@ -158,8 +159,24 @@ def test_native_glue_loads_and_fails_loudly_on_cpu_tensors():
     with pytest.raises(TypeError):
         g.uniform([1.0, 2.0], 16, 256, False, 0.0, False, 0, False, False)
     import quantization
-    with pytest.raises(RuntimeError, match='no CPU path'):
-        quantization.uniformQuantization(torch.zeros(8), 16, bucket_size=4)
+    q, _ = quantization.uniformQuantization(torch.zeros(8), 16, bucket_size=4)       # ... and the API does not send them there
+    assert q.device.type == 'cpu' and torch.equal(q, torch.zeros(8))
+
+
+def test_host_library_exports_its_entry_points_with_the_header_signatures():
+    """libqd_host.so: every symbol of _lib.HOST_SYMBOLS is exported, declared in include/qd_hip.h under the same name, and the
+    library identifies itself as the host build of the same ABI version."""
+    h = _lib.host()
+    assert h.qd_abi_version() == _lib.ABI_VERSION and h.qd_target_arch() == b'host' and h.qd_host_max_threads() >= 1
+    header = open(os.path.join(_lib.INCLUDE, 'qd_hip.h')).read()
+    for name in _lib.HOST_SYMBOLS:
+        assert hasattr(h, name), name
+        assert re.search(r'\b%s\s*\(' % name, header), name
+    exported = subprocess.run(['nm', '-D', '--defined-only', _lib.HOST_LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    names = {l.split()[-1] for l in exported.splitlines() if ' T ' in l}
+    assert names == set(_lib.HOST_SYMBOLS) | {'qd_host_max_threads'}, names ^ (set(_lib.HOST_SYMBOLS) | {'qd_host_max_threads'})
+    assert h.qd_num_buckets(1000, 256) == 4 and h.qd_padded_length(1000, 256) == 1024 and h.qd_num_buckets(100, 256) == 1
+    assert h.qd_uniform_f32(None, None, 10, 256, 16, None, None, None, None, 0, 0.0, 0, 0, None, 0, None) == -1
 
 
 def test_glue_common_path_declines_what_it_does_not_handle():
@@ -179,8 +196,7 @@ def test_glue_common_path_declines_what_it_does_not_handle():
                  (x, 16, True), (x, 16, 0), (x, 16, -1), (x, 1, 4), (x, 2 ** 40, 4), (x, 16, 2 ** 70), ('x', 16, 4),
                  (x, 16), (x, 16, 4, 5)):
         assert g.uniform_common(*args) is None, args
-    with pytest.raises(RuntimeError, match='no CPU path'):
-        quantization.uniformQuantization(x, 16, bucket_size=4)
+    assert quantization.uniformQuantization(x, 16, bucket_size=4)[0].device.type == 'cpu'       # (CPU tensors: libqd_host.so)
     with pytest.raises(ValueError):
         quantization.uniformQuantization(x, 16, bucket_size=True)
 

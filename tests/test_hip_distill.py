@@ -160,8 +160,9 @@ def test_ste_python_api_matches_torch_ops():
     want_g[w.abs() > 1] = 0
     assert torch.equal(ste.truncated_ste_(gr.clone(), w), want_g)
     assert torch.equal(ste.clamp_(w.clone()), w.clamp(-1, 1))
-    with pytest.raises(RuntimeError):
-        ste.clamp_(torch.zeros(4))                          # CPU tensor: no CPU path
+    assert torch.equal(ste.clamp_(torch.tensor([2.0, -3.0, 0.5])), torch.tensor([1.0, -1.0, 0.5]))     # CPU tensor: libqd_host.so
+    with pytest.raises(TypeError):
+        ste.clamp_(torch.zeros(4, dtype=torch.float64, device=DEV))
 
 
 def _settle_miopen(shapes=(16,)):

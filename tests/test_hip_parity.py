@@ -515,6 +515,11 @@ def test_nonuniform_golden(golden_nonuniform):
         # list of python floats and CPU tensor of points are accepted too
         q_l, idx_l, _ = quantization.nonUniformQuantization(xd, [float(v) for v in pts], bucket_size=c['bucket'])
         assert torch.equal(q_l, q) and torch.equal(idx_l, idx)
+        # the one-byte index form (index_dtype=torch.uint8, an opt-in): same values, same indices after .long()
+        if c['k'] <= 256:
+            q8, idx8, sf8 = quantization.nonUniformQuantization(xd, dev(pts), bucket_size=c['bucket'], index_dtype=torch.uint8)
+            assert idx8.dtype == torch.uint8 and idx8.shape == xd.shape, tag
+            assert torch.equal(idx8.long(), idx) and torch.equal(q8, q) and torch.equal(sf8.alpha, sf.alpha), tag
         # pre-processed variable: midpoint rule, first and second query, gradients
         fn = quantization.nonUniformQuantization_variable(bucket_size=c['bucket'], pre_process_tensors=True, tensor=xd)
         qp = fn.forward(None, dev(pts))
@@ -549,6 +554,12 @@ def test_nonuniform_random_vs_c_oracle(k):
             r = oc.nonuniform_quantize(x, pts, bucket, mode)
             if mode == 'distance':
                 q, idx, sf = quantization.nonUniformQuantization(dev(x), dev(pts), bucket_size=bucket)
+                if k <= 256:
+                    q8, idx8, _ = quantization.nonUniformQuantization(dev(x), dev(pts), bucket_size=bucket, index_dtype=torch.uint8)
+                    assert idx8.dtype == torch.uint8 and torch.equal(idx8.long(), idx) and torch.equal(q8, q), (n, bucket, k)
+                else:
+                    with pytest.raises(ValueError, match='256'):
+                        quantization.nonUniformQuantization(dev(x), dev(pts), bucket_size=bucket, index_dtype=torch.uint8)
             else:
                 fn = quantization.nonUniformQuantization_variable(bucket_size=bucket, pre_process_tensors=True, tensor=dev(x))
                 q = fn.forward(None, dev(pts))
@@ -723,7 +734,7 @@ def test_init_points_and_huffman_golden(golden_misc):
     for i, c in enumerate(G.meta['init_points']):
         sf = quantization.ScalingFunction('linear', False, False, c['bucket'], False)
         p = qhf.initialize_quantization_points(dev(G.z['ip%d_x' % i]), sf, c['k'])
-        assert p.is_cuda and np.array_equal(host(p), G.z['ip%d_p' % i]), c
+        assert p.device == dev(np.zeros(1, np.float32)).device and np.array_equal(host(p), G.z['ip%d_p' % i]), c
     params = [dev(G.z['hf_p%d' % j]) for j in range(4)]
     for c in G.meta['huffman']:
         if c['kind'] == 'uniform':
@@ -771,14 +782,14 @@ def test_ste_complicated_large_vs_c_oracle():
 
 
 def test_truncated_ste_kernels():
-    lib = _lib.load()
     rng = np.random.RandomState(3)
     w = (rng.randn(100001) * 0.8).astype(np.float32)
     g = rng.randn(100001).astype(np.float32)
     wd, gd = dev(w), dev(g)
-    _lib.check(lib.qd_truncated_ste_f32(wd.data_ptr(), gd.data_ptr(), w.size, 1.0, _lib.stream_ptr()))
+    lib = _lib.lib_for(wd)                       # the library of the tensors' device (tests/test_host_parity.py runs this on CPU tensors)
+    _lib.check(lib.qd_truncated_ste_f32(wd.data_ptr(), gd.data_ptr(), w.size, 1.0, _lib.stream_for(wd)))
     assert np.array_equal(host(gd), onp.truncated_ste_mask(w, g))
-    _lib.check(lib.qd_clamp_f32(wd.data_ptr(), w.size, 1.0, _lib.stream_ptr()))
+    _lib.check(lib.qd_clamp_f32(wd.data_ptr(), w.size, 1.0, _lib.stream_for(wd)))
     assert np.array_equal(host(wd), np.clip(w, -1.0, 1.0))
 
 
@@ -1115,9 +1126,10 @@ def test_nonfinite_inputs_golden(golden_nonfinite):
         assert np.array_equal(host(q), G.arr('f', i, 'q'), equal_nan=True), (i, c)
         assert np.array_equal(host(sf.alpha), G.arr('f', i, 'alpha'), equal_nan=True), (i, c)
         assert np.array_equal(host(sf.beta), G.arr('f', i, 'beta'), equal_nan=True), (i, c)
-        out = MultiTensorQuantizer([xd], c['s'], c['bucket']).quantize()[0]
-        assert np.array_equal(host(out), G.arr('f', i, 'q'), equal_nan=True), (i, c)
-        if c['bucket'] == 256:
+        if xd.is_cuda:                               # (multi-tensor launches and the codec exist for device tensors only)
+            out = MultiTensorQuantizer([xd], c['s'], c['bucket']).quantize()[0]
+            assert np.array_equal(host(out), G.arr('f', i, 'q'), equal_nan=True), (i, c)
+        if c['bucket'] == 256 and xd.is_cuda:
             assert np.array_equal(host(codec.pack_uniform(xd, c['s'], 256).alpha), G.arr('f', i, 'alpha').reshape(-1), equal_nan=True)
         sf2 = quantization.ScalingFunction('linear', False, False, c['bucket'])
         u = sf2.scale_down(xd)
@@ -1424,7 +1436,7 @@ def test_quantize_bit_exact_at_extreme_scales(bucket):
             got = host(q)
             assert np.array_equal(got, want['q'], equal_nan=True), (bucket, ci, s, int(np.sum(got != want['q'])))
             assert np.array_equal(host(sf.alpha).reshape(-1), want['alpha'], equal_nan=True)
-        seed = qf.next_stochastic_seed(peek=True)
+        seed = qf.next_stochastic_seed(peek=True, host=not dev(x[:1]).is_cuda)
         qs, _ = quantization.uniformQuantization(dev(x), 16, stochastic_rounding=True, bucket_size=bucket)
         nb, row, padded = onp.bucket_geometry(n, bucket)
         rand = np.zeros(padded, np.float32)

@@ -1,6 +1,7 @@
 """Host-side behaviour of the `quantization` mirror that needs no GPU: argument validation and
-exceptions (same as the reference), pure-host helpers against golden values, and the loud
-failure on CPU tensors (this package has no CPU path)."""
+exceptions (same as the reference), pure-host helpers against golden values, and what happens to
+tensors that are not on a HIP device: CPU fp32 tensors are computed by libqd_host.so (tests/test_host_parity.py),
+anything else fails loudly -- as do the device-only entry points on CPU tensors."""
 import numpy as np
 import pytest
 import torch
@@ -33,14 +34,27 @@ def test_scaling_function_validation():
     assert sf.tol_diff_zero == 1e-10 and sf.alpha is None and sf.bucket_size == 256
 
 
-def test_cpu_tensors_fail_loudly():
+def test_one_library_per_device_and_loud_failures():
+    """A CPU fp32 tensor is computed by libqd_host.so and the result stays on the CPU (parity: tests/test_host_parity.py);
+    what has no host library -- other dtypes, meta tensors, the multi-tensor / codec entry points -- raises."""
     x = torch.randn(100)
-    with pytest.raises(RuntimeError, match='HIP device'):
-        quantization.uniformQuantization(x, 16, bucket_size=256)
-    with pytest.raises(RuntimeError, match='HIP device'):
-        quantization.nonUniformQuantization(x, [0.0, 1.0])
-    with pytest.raises(RuntimeError, match='HIP device'):
-        quantization.ScalingFunction('linear', False, False, None).scale_down(x)
+    q, sf = quantization.uniformQuantization(x, 16, bucket_size=256)
+    assert q.device.type == 'cpu' and sf.alpha.device.type == 'cpu' and q.shape == x.shape
+    assert quantization.nonUniformQuantization(x, [0.0, 1.0])[1].dtype == torch.int64
+    assert quantization.ScalingFunction('linear', False, False, None).scale_down(x).device.type == 'cpu'
+    with pytest.raises(TypeError, match='float32'):
+        quantization.uniformQuantization(x.double(), 16, bucket_size=256)
+    with pytest.raises(TypeError, match='float32'):
+        quantization.ScalingFunction('linear', False, False, None).scale_down(x.half())
+    with pytest.raises(RuntimeError, match='HIP device or on the CPU'):
+        quantization.uniformQuantization(torch.empty(100, device='meta'), 16, bucket_size=256)
+    from quantized_distillation_amd import codec
+    from quantized_distillation_amd.multi_tensor import MultiTensorDiffQuant, MultiTensorQuantizer
+    for call in (lambda: MultiTensorQuantizer([x], 16, 256), lambda: codec.pack_uniform(x, 16, 256),
+                 lambda: MultiTensorDiffQuant([x], [torch.empty(100)], [torch.empty(100)], 4, 256)):
+        with pytest.raises(RuntimeError, match='HIP device'):
+            call()
+    assert _lib.lib_for(x) is _lib.host() and _lib.stream_for(x) is None
 
 
 def test_nonuniform_argument_errors():
