@@ -102,6 +102,23 @@ def cpu_baseline(x_host, q_gpu, alpha_gpu, budget_s=2.0, with_ports=True):
         bit_exact = bool(np.array_equal(q_gpu, q_ref.numpy()) and
                          np.array_equal(alpha_gpu, sf_ref.alpha.numpy().reshape(-1)))
         out['gpu_result_bit_exact_vs_reference'] = bit_exact
+        # next to the baseline, NOT a baseline: what the PRODUCT does with the same CPU tensor (libqd_host.so, the library CPU
+        # tensors are computed by -- the same API call on a tensor that lives on the host), and that its result is the reference's
+        try:
+            import quantization
+            from quantized_distillation_amd import _lib
+            th = min(ncpu, 64)
+            _lib.host().qd_host_set_threads(th)
+            tp = _time_runs(lambda: quantization.uniformQuantization(x_host, LEVELS, bucket_size=BUCKET), 3, 1.0)
+            q_host, sf_host = quantization.uniformQuantization(x_host, LEVELS, bucket_size=BUCKET)
+            out['product_on_cpu_tensors'] = {
+                'value': round(ALGO_BYTES_PER_ELEM * n / min(tp) / 1e9, 3), 'unit': 'GB/s', 'threads': th,
+                'bit_exact_vs_reference': bool(torch.equal(q_host, q_ref) and torch.equal(sf_host.alpha, sf_ref.alpha)),
+                'sample': '%d runs, min %.4f s; quantization.uniformQuantization on the CPU tensor -> libqd_host.so (csrc/host/qd_host.cpp, OpenMP)'
+                          % (len(tp), min(tp))}
+            del q_host, sf_host
+        except Exception as e:                                    # noqa: BLE001 -- a side figure
+            out['product_on_cpu_tensors'] = {'error': '%s: %s' % (type(e).__name__, e)}
         del q_ref, sf_ref
     else:
         out['reference_error'] = ('oracle/_ref is not staged (run __graft_entry__.build() where /root/reference exists); '

@@ -152,6 +152,8 @@ def host():
             fn.argtypes = args
         lib.qd_host_max_threads.restype = c_int
         lib.qd_host_max_threads.argtypes = []
+        lib.qd_host_set_threads.restype = None
+        lib.qd_host_set_threads.argtypes = [c_int]
         if lib.qd_abi_version() != ABI_VERSION:
             raise RuntimeError('libqd_host.so has ABI version %d, this binding is written for %d: rebuild it '
                                '(python -c "import __graft_entry__ as g; g.build()")' % (lib.qd_abi_version(), ABI_VERSION))

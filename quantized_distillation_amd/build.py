@@ -135,7 +135,7 @@ def build_glue(force=False, verbose=False):
     return out
 
 
-HOST_FLAGS = ['-O2', '-std=c++17', '-fPIC', '-shared', '-fopenmp',
+HOST_FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', '-fopenmp',
               '-ffp-contract=off', '-fno-fast-math',     # as the device build: every fp32 op rounded separately, no reassociation
               '-fvisibility=hidden',                      # only the extern "C" entry points leave the library ...
               '-Wl,-Bsymbolic-functions']                 # ... and its own calls to them never resolve into libqd_hip.so (same names)

@@ -62,12 +62,18 @@ inline void range_minmax(const float* x, int64_t lo, int64_t hi, const Prep& pp,
     mn = std::numeric_limits<float>::infinity();
     mx = -mn;
     nan = false;
+    const float mean = pp.mean, me = pp.me;
+    int nans = 0;
+#pragma omp simd reduction(min : mn) reduction(max : mx) reduction(| : nans)
     for (int64_t i = lo; i < hi; ++i) {
-        const float v = pp(x[i]);
-        nan |= (v != v);
+        float v = x[i] - mean;
+        v = v > me ? me : v;
+        v = v < -me ? -me : v;
+        nans |= (v != v) ? 1 : 0;
         mn = v < mn ? v : mn;
         mx = v > mx ? v : mx;
     }
+    nan = nans != 0;
 }
 inline void alpha_beta(float mn, float mx, bool nan, float& a, float& b) {
     if (nan) { mn = std::numeric_limits<float>::quiet_NaN(); mx = mn; }
@@ -118,12 +124,22 @@ inline float philox_uniform(uint64_t seed, int64_t e) {
     return r4[e & 3];
 }
 
+// rintf() without the libm call (the baseline x86-64 ISA has no rounding instruction, so std::nearbyintf is a function call
+// per element and the loop does not vectorise): below 2^23 adding and subtracting 2^23 rounds to an integer in the current
+// (default: nearest-even) mode, exactly; from 2^23 on every float is an integer.  The sign is kept (-0.4 -> -0.0, as rintf).
+// NaN: the comparison is false, t itself is returned.  (No -ffast-math: the compiler may not fold (a + c) - c.)
+inline float rint_even(float t) {
+    const float a = std::fabs(t);
+    const float r = (a + 8388608.0f) - 8388608.0f;
+    return a < 8388608.0f ? std::copysign(r, t) : t;
+}
+
 // the k-level quantize-dequantize of one element: seven separately rounded fp32 ops (:106-107,189-191,142-148)
 inline float qdq(float v, float a, float b, float sm1, float mean, float& level) {
     float u = v - b;
     u = u / a;
     float t = u * sm1;
-    float r = std::nearbyintf(t);                     // round half to even (the default rounding mode), torch.round
+    float r = rint_even(t);                           // round half to even, torch.round
     level = r;
     float w = r / sm1;
     float y = w * a;
@@ -211,11 +227,19 @@ size_t qd_workspace_bytes(void) { return 16; }        // nothing on the host nee
 int64_t qd_num_buckets(int64_t n, int64_t bucket) { int64_t nb, row; geometry(n, bucket, nb, row); return nb; }
 int64_t qd_padded_length(int64_t n, int64_t bucket) { int64_t nb, row; geometry(n, bucket, nb, row); return nb * row; }
 
+// (the two symbols below exist in this library only: OpenMP threads of the host loops)
 int qd_host_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
 #else
     return 1;
+#endif
+}
+void qd_host_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
 #endif
 }
 
@@ -262,7 +286,21 @@ int qd_uniform_f32(const float* x, float* q, int64_t n, int64_t bucket, int leve
         if (beta) beta[bk] = b;
     };
     auto body = [&](int64_t, int64_t lo, int64_t hi, float a, float b) {
-        for (int64_t i = lo; i < hi; ++i) {                                         // (q may alias x: element i is read before it is written)
+        if (!stochastic && !level_idx) {
+            // the per-step case: a branch-free loop the compiler vectorises (IEEE vector division; q may alias x exactly --
+            // element i is read before it is written, no dependence between iterations)
+            const float mean = pp.mean, me = pp.me;
+#pragma omp simd
+            for (int64_t i = lo; i < hi; ++i) {
+                float v = x[i] - mean;
+                v = v > me ? me : v;
+                v = v < -me ? -me : v;
+                float lev;
+                q[i] = qdq(v, a, b, sm1, mean, lev);
+            }
+            return;
+        }
+        for (int64_t i = lo; i < hi; ++i) {
             float lev;
             const float v = pp(x[i]);
             q[i] = stochastic ? qdq_stochastic(v, a, b, sm1, pp.mean, philox_uniform(seed, i), lev) : qdq(v, a, b, sm1, pp.mean, lev);
@@ -296,15 +334,19 @@ int qd_scale_down_f32(const float* x, float* u, int64_t n, int64_t bucket, float
         beta[bk] = b;
     };
     auto body = [&](int64_t, int64_t lo, int64_t hi, float a, float b) {
-        float last = 0.0f;
+        const float mean = pp.mean, me = pp.me;
+#pragma omp simd
         for (int64_t i = lo; i < hi; ++i) {
-            float v = pp(x[i]) - b;                                                 // :106-107
-            v = v / a;
-            u[i] = v;
-            last = v;
+            float v = x[i] - mean;
+            v = v > me ? me : v;
+            v = v < -me ? -me : v;
+            v = v - b;                                                              // :106-107
+            u[i] = v / a;
         }
-        if (hi == n && nb > 1)                                                      // padding: the scaled last element (help_functions.py:76-86)
+        if (hi == n && nb > 1) {                                                    // padding: the scaled last element (help_functions.py:76-86)
+            const float last = u[n - 1];
             for (int64_t i = n; i < nb * row; ++i) u[i] = last;
+        }
     };
     for_buckets(n, nb, row, stats, body);
     return 0;
@@ -320,6 +362,7 @@ int qd_inv_scale_f32(const float* u, float* y, int64_t n, int64_t bucket, const 
     const float m = mean ? *mean : 0.0f;
     auto stats = [&](int64_t bk, int64_t, int64_t, float& a, float& b, bool) { a = alpha[bk]; b = beta[bk]; };
     auto body = [&](int64_t, int64_t lo, int64_t hi, float a, float b) {
+#pragma omp simd
         for (int64_t i = lo; i < hi; ++i) {
             float r = u[i] * a;                                                     // :142-143, two ops
             r = r + b;

@@ -141,8 +141,9 @@ def test_everything_else_takes_the_general_path():
             quantization.uniformQuantization(x, 16, bucket_size=bad)
     with pytest.raises(ValueError):
         quantization.uniformQuantization(x, 1, bucket_size=256)
-    with pytest.raises(RuntimeError):
-        quantization.uniformQuantization(x.cpu(), 16, bucket_size=256)
+    # a CPU tensor: computed by libqd_host.so, result on the CPU, the same bits as the device's
+    q_cpu, sf_cpu = quantization.uniformQuantization(x.cpu(), 16, bucket_size=256)
+    assert q_cpu.device.type == 'cpu' and torch.equal(q_cpu, want_q.cpu()) and torch.equal(sf_cpu.alpha, want_sf.alpha.cpu())
     with pytest.raises(TypeError):
         quantization.uniformQuantization(x.double(), 16, bucket_size=256)
     # in place, clamp, mean, stochastic: general path, untouched behaviour
