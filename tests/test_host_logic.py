@@ -225,10 +225,17 @@ def test_committed_bench_lines_keep_the_contract_and_are_self_consistent():
     import os
     from harness.dpbench import DP_KEYS
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r04_bench*.json')))
-    assert len(files) >= 3
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r05_bench*.json')))
+    assert len(files) >= 5                              # the driver's command on five fresh leases (+ the other launch modes)
     for f in files:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
+        lines = [l for l in open(f).read().splitlines() if l.strip()]
+        assert len(lines) == 1, (f, 'ONE line on stdout')
+        d = json.loads(lines[0])
+        if 'driver' in os.path.basename(f):
+            bp = d['bench_process']                          # what the guardian saw: one worker, clean exit, nothing lost
+            assert bp['restarts'] == 0 and bp['workers'][-1]['exit'] == 0 and 'legs_lost_with_their_worker' not in bp, (f, bp)
+            assert d['cpu_baseline']['kind'] == 'reference' and d['cpu_baseline']['cores'] >= 1 and d['parity_bit_exact_vs_reference'] is True
+            assert list(d)[-1] == 'roofline' and isinstance(d['roofline'].get('legs_wall_s'), str)
         for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
                     'dtype', 'data', 'config', 'roofline'):
             assert key in d, (f, key)

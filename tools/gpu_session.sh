@@ -4,7 +4,7 @@
 #   smoke      __graft_entry__.smoke()
 #   tests      the whole GPU suite (records the achieved reduction errors in gpurun_out/reduction_error.jsonl)
 #   bench      bench.py with the default flags, then with the driver's (--steps 20 --warmup 5)
-#   prof       rocprofv3 --kernel-trace --stats of the bench command + the two PMC passes (FETCH_SIZE, WRITE_SIZE)
+#   prof       rocprofv3 --kernel-trace --stats of the bench command (its measuring process, `bench.py --worker`, run directly) + the two PMC passes (FETCH_SIZE, WRITE_SIZE)
 #   kernels    tools/bench_kernels.py (every kernel of the path, steady state)
 #   pmck       per-kernel PMC traffic of tools/pmc_probe.py
 #   div        tools/div_invariant_check.py --pairs 1e9 (the long run of the division proof)
@@ -47,9 +47,9 @@ for step in "$@"; do
              find gpurun_out/kprof_stats -name '*.csv' -size +4M -delete
              head -12 gpurun_out/kernels_rocprof_stats.csv | cut -c1-200 ;;
     prof)    rm -rf gpurun_out/prof_stats gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
-             (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o bench -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-distill --no-pmc --no-kernels > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "stats rc=$?"
+             (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o bench -- python $R/bench.py --worker --steps 100 --warmup 10 --no-cpu-baseline --no-distill --no-pmc --no-kernels > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "stats rc=$?"
              for c in FETCH_SIZE WRITE_SIZE; do
-               (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o bench -- python $R/bench.py --steps 10 --warmup 2 --precondition-s 0.05 --no-cpu-baseline --no-distill --no-pmc --no-kernels > /dev/null 2> $R/gpurun_out/pmc_$c.err); echo "pmc $c rc=$?"
+               (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -o bench -- python $R/bench.py --worker --steps 10 --warmup 2 --precondition-s 0.05 --no-cpu-baseline --no-distill --no-pmc --no-kernels > /dev/null 2> $R/gpurun_out/pmc_$c.err); echo "pmc $c rc=$?"
              done ;;
     pmck)    rm -rf gpurun_out/pmcK_FETCH_SIZE gpurun_out/pmcK_WRITE_SIZE
              for c in FETCH_SIZE WRITE_SIZE; do
