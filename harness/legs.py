@@ -16,9 +16,16 @@ TORCH_NCCL_ASYNC_ERROR_HANDLING=2 the watchdog aborts the communicator and the b
 raises instead of tearing the process down), raise, and enter the same agreement.  Once a
 rank has failed INSIDE a leg, the data-path communicator may hold unmatched collectives, so
 every later collective-bearing leg is skipped (recorded as such) and the final JSON line is
-still printed.  `Deadline` is the backstop for the second case: a daemon thread that, when
-the whole run exceeds its budget, has rank 0 print what has been measured so far and ends
-the process.
+still printed.  The backstop for the second case is the wall limit of the process that owns the
+line (harness/guardian.py: it ends the worker and prints what had been measured); `Deadline`
+below is the in-process form of the same idea, kept for scripts without a guardian.
+
+What the agreement guarantees whatever RCCL's watchdog does (mode 2 "CleanUpOnly" aborts the
+communicator; whether the blocked wait() then RAISES or merely returns is not something a
+one-GPU box can show): a leg's result is reported only if EVERY rank finished the leg.  A rank
+whose aborted collective returned without raising may compute on garbage, but the rank that
+caused the abort has said "failed" in the agreement, so every rank -- that one included --
+replaces its result with the error record.  Untested on RCCL with N > 1 (no such box yet).
 
 Device-agnostic: tests/test_legs_gloo.py runs two gloo ranks on CPU, one of which raises inside a
 leg, and checks that both leave within seconds with the error in rank 0's JSON line.
