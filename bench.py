@@ -255,6 +255,14 @@ def worker_main(args):
             from harness.kernel_bench import flat_row
             for i, row in enumerate(r['kernels']):
                 r['k%02d' % (i + 1)] = flat_row(row)
+        c0 = (line.get('cpu_baseline') or {}).get('distill') if isinstance(line.get('cpu_baseline'), dict) else line.get('cpu_distill')
+        if isinstance(c0, dict) and 'steps_per_sec' in c0:
+            pr = c0.get('product_on_cpu_tensors') or {}
+            r['steps_cfg0_cpu'] = ('reference quantizer %.2f steps/s (quantize %.1f ms/step, %d threads)' % (
+                c0['steps_per_sec'], c0['quantize_ms_per_step'], c0.get('threads', 0)) + (
+                ' | this package on CPU tensors %.2f (quantize %.1f ms/step), same weights: %s' % (
+                    pr['steps_per_sec'], pr['quantize_ms_per_step'], pr.get('weights_after_training_bit_identical_to_the_reference_run'))
+                if 'steps_per_sec' in pr else ''))[:236]
         r['legs_wall_s'] = ' '.join('%s=%s' % (k, v) for k, v in wall.items())[:236]
         r['wall_s'] = round(time.time() - t_start, 1)
         line['roofline'] = line.pop('roofline')                    # last: the driver keeps the tail of the line

@@ -149,58 +149,83 @@ def cpu_baseline(x_host, q_gpu, alpha_gpu, budget_s=2.0, with_ports=True):
 
 
 def cpu_distill_baseline(steps=60, warmup=3, batch=50):
-    """BASELINE configs[0]: the CIFAR10 ConvolForwardNet student step on the CPU with the
-    reference's own quantizer (staged bytecode; its torch-op port when nothing is staged) in the
-    reference's loop shape (quantize every parameter, fwd/bwd with the KD loss, restore, SGD).  A bounded sample (60 of
-    the 200 steps of configs[0]'s "1 epoch synthetic" = 10000 images / batch 50; --cpu-distill-steps 200
-    runs the whole epoch): steps/sec does not depend on how many are timed."""
+    """BASELINE configs[0]: the CIFAR10 ConvolForwardNet student step on the CPU in the reference's loop shape (quantize
+    every parameter, fwd/bwd with the KD loss, restore, SGD) -- with the reference's own quantizer (staged bytecode; its
+    torch-op port when nothing is staged): THE BASELINE -- and, beside it, the same loop with this package's quantizer on
+    the same CPU tensors (libqd_host.so): the product on configs[0].  A bounded sample (`steps` of the 200 steps of
+    configs[0]'s "1 epoch synthetic" = 10000 images / batch 50, BASELINE.md 4.4, split between the two; --cpu-distill-steps
+    400 runs the whole epoch for each): steps/sec does not depend on how many are timed."""
     from . import models
     from oracle import ref_stage
     from oracle.torch_port import uniform_quantize_torch_ops
     refq = ref_stage.load()
     if refq is not None:
-        def quantize_one(t):
+        def reference_quantizer(t):
             return refq.uniformQuantization(t, 16, bucket_size=256)[0]
     else:
-        def quantize_one(t):
+        def reference_quantizer(t):
             return uniform_quantize_torch_ops(t, 16, 256)[0]
-    torch.manual_seed(0)
+
+    def product_quantizer(t):
+        import quantization
+        return quantization.uniformQuantization(t, 16, bucket_size=256)[0]
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
-    st, te = models.student().train(), models.teacher().eval()
-    opt = torch.optim.SGD(st.parameters(), lr=1e-3, momentum=0.9, nesterov=True, weight_decay=2.2e-4)
+    try:
+        from quantized_distillation_amd import _lib
+        _lib.host().qd_host_set_threads(threads)
+    except Exception:                                             # noqa: BLE001 -- the product leg below reports it
+        pass
     g = torch.Generator().manual_seed(0)
     x, y = torch.randn(batch, 3, 32, 32, generator=g), torch.randint(0, 10, (batch,), generator=g)
-    t_quant = 0.0
 
-    def one():
-        nonlocal t_quant
-        a = time.perf_counter()
-        saved = [p.data for p in st.parameters()]
-        for p in st.parameters():
-            p.data = quantize_one(p.data)
-        t_quant += time.perf_counter() - a
-        opt.zero_grad()
-        with torch.no_grad():
-            t_out = te(x)
-        models.kd_loss(st(x), t_out, y).backward()
-        for p, m in zip(st.parameters(), saved):
-            p.data = m
-        opt.step()
+    def run(quantize_one, n_steps):
+        torch.manual_seed(0)
+        st, te = models.student().train(), models.teacher().eval()
+        opt = torch.optim.SGD(st.parameters(), lr=1e-3, momentum=0.9, nesterov=True, weight_decay=2.2e-4)
+        t_quant = [0.0]
 
-    for _ in range(warmup):
-        one()
-    t_quant = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    dt = time.perf_counter() - t0
-    return {'steps_per_sec': round(steps / dt, 3), 'ms_per_step': round(dt / steps * 1e3, 2),
-            'quantize_ms_per_step': round(t_quant / steps * 1e3, 3), 'threads': threads,
-            'quantizer': 'reference (oracle/_ref bytecode)' if refq is not None else 'torch-op port (oracle/torch_port.py)',
-            'sample': '%d steps (of the 200 of one synthetic epoch: 10000 images) after %d warm-up steps, batch %d, synthetic '
-                      'CIFAR10-shaped data; student+teacher fwd, KD loss, bwd, SGD on the host with the reference quantizer in the '
-                      'loop (configs[0])' % (steps, warmup, batch)}
+        def one():
+            a = time.perf_counter()
+            saved = [p.data for p in st.parameters()]
+            for p in st.parameters():
+                p.data = quantize_one(p.data)
+            t_quant[0] += time.perf_counter() - a
+            opt.zero_grad()
+            with torch.no_grad():
+                t_out = te(x)
+            models.kd_loss(st(x), t_out, y).backward()
+            for p, m in zip(st.parameters(), saved):
+                p.data = m
+            opt.step()
+
+        for _ in range(warmup):
+            one()
+        t_quant[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            one()
+        dt = time.perf_counter() - t0
+        final = torch.cat([p.detach().reshape(-1) for p in st.parameters()])
+        return {'steps_per_sec': round(n_steps / dt, 3), 'ms_per_step': round(dt / n_steps * 1e3, 2),
+                'quantize_ms_per_step': round(t_quant[0] / n_steps * 1e3, 3), 'steps': n_steps}, final
+
+    half = max(1, steps // 2)
+    base, w_ref = run(reference_quantizer, half)
+    out = dict(base)
+    out.update({'threads': threads,
+                'quantizer': 'reference (oracle/_ref bytecode)' if refq is not None else 'torch-op port (oracle/torch_port.py)',
+                'sample': '%d steps (of the 200 of one synthetic epoch: 10000 images) after %d warm-up steps, batch %d, synthetic '
+                          'CIFAR10-shaped data; student+teacher fwd, KD loss, bwd, SGD on the host with the reference quantizer in the '
+                          'loop (configs[0])' % (half, warmup, batch)})
+    try:
+        prod, w_prod = run(product_quantizer, half)
+        prod['quantizer'] = 'this package on the same CPU tensors (libqd_host.so)'
+        prod['weights_after_training_bit_identical_to_the_reference_run'] = bool(torch.equal(w_ref, w_prod))
+        out['product_on_cpu_tensors'] = prod
+    except Exception as e:                                        # noqa: BLE001
+        out['product_on_cpu_tensors'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
 
 
 CIFAR_DESC = ('CIFAR10-shaped synthetic randn(B,3,32,32), ConvolForwardNet student (22 tensors, 1.00 M params) distilled from the '
