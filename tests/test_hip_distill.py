@@ -313,3 +313,43 @@ def test_diffquant_automatic_point_counts():
         la, lb = a.step(xs, ys), b.step(xs, ys)
         assert bool(torch.isfinite(lb)) and abs(float(la) - float(lb)) < 1e-3 * max(1.0, abs(float(la)))
     assert torch.equal(torch.isinf(b.points), pad) and torch.equal(torch.isinf(a.points), pad)
+
+
+@pytest.mark.parametrize('ntensors,k', [(7, 4), (64, 4), (65, 4), (130, 16), (40, 64), (3, 2)])
+def test_multi_tensor_point_gradient_on_adversarial_shape_lists(ntensors, k):
+    """qd_multi_point_grad_f32 (csrc/qd_multi_dq.hip: one strided sequence of full 1024-element tiles over all tensors, extra
+    waves for what is left of each tensor) on lists of 3 ... 130 tensors that mix tensors below one tile, exact multiples of 1024, ragged ones, one large tensor and views at odd
+    offsets -- against the per-tensor K6 call (same fp32 products, another summation order) and a float64 sum; bit-identical
+    over 20 launches; the forward sweep bit-exact against the per-tensor K5 call."""
+    import quantization
+    from quantized_distillation_amd.multi_tensor import MultiTensorDiffQuant
+    rng = np.random.RandomState(1000 * ntensors + k)
+    sizes = [int(s) for s in rng.choice([1, 3, 255, 256, 257, 1023, 1024, 1025, 2048, 4097, 10000, 65536, 100003], ntensors)]
+    sizes[rng.randint(ntensors)] = 3 * 1024 * 1024 + 5
+    if ntensors > 2:
+        sizes[0], sizes[-1] = 5, 1024 * 7
+    gen = torch.Generator().manual_seed(ntensors)
+    base = [torch.randn(n + 3, generator=gen).to(DEV) for n in sizes]
+    ws = [b[(i % 2) * 3:(i % 2) * 3 + n] if n > 4000 else b[:n].clone() for i, (b, n) in enumerate(zip(base, sizes))]    # some at +12 B
+    ws = [w.contiguous() if w.data_ptr() % 4 else w for w in ws]
+    outs = [torch.empty(n, device=DEV) for n in sizes]
+    grads = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
+    mt = MultiTensorDiffQuant(ws, outs, grads, k, 256)
+    pts = torch.sort(torch.rand(ntensors, k, generator=gen), dim=1)[0].to(DEV)
+    mt.forward(pts)
+    got = mt.backward()
+    again = [mt.backward() for _ in range(20)]
+    assert all(torch.equal(a, got) for a in again), 'not deterministic'
+    for i, (w, g) in enumerate(zip(ws, grads)):
+        fn = quantization.nonUniformQuantization_variable(bucket_size=256, pre_process_tensors=True, tensor=w)
+        q = fn.forward(None, pts[i])
+        assert torch.equal(q.view(-1), outs[i]), (i, sizes[i])
+        assert torch.equal(fn.savedForBackward.raw_indices().view(-1), mt.indices[i]), (i, sizes[i])
+        _, gp = fn.backward(g)
+        alpha = fn.scaling_function.alpha.reshape(-1)
+        a_e = alpha.repeat_interleave(256)[:sizes[i]] if sizes[i] > 256 else alpha[0].expand(sizes[i])
+        prod = (g * a_e).double()                                   # the fp32 products, exactly
+        want = torch.zeros(k, dtype=torch.float64, device=DEV).index_add_(0, mt.indices[i].long(), prod)
+        scale = float(prod.abs().sum()) + 1e-30
+        assert float((got[i].double() - want).abs().max()) <= 1e-6 * scale, (i, sizes[i])
+        assert float((gp.double() - want).abs().max()) <= 1e-6 * scale, (i, sizes[i])
