@@ -190,3 +190,13 @@ def test_stochastic_rounding_draws_the_device_generators_numbers():
         w = np.float32(np.float32(lo / sm1) + (np.float32(np.float32(1.0) / sm1) if up else np.float32(0.0)))
         want = np.float32(np.float32(np.float32(w * a) + b) + np.float32(0.0))
         assert np.float32(q[e]) == want, e
+
+
+@pytest.mark.parametrize('name', ['test_uniform_matches_oracle', 'test_nonuniform_matches_oracle', 'test_ste_backward_matches_oracle',
+                                  'test_uniform_subtract_mean_matches_oracle'])
+def test_property_suite_on_cpu_tensors(name, monkeypatch):
+    """The device-independent hypothesis properties of tests/test_hip_property.py (random sizes, 35 bucket sizes, level / point
+    counts, nine value distributions incl. denormals, huge ranges and all-ties, clamp, mean) with every tensor on the CPU."""
+    import test_hip_property as PP
+    monkeypatch.setattr(PP, 'DEV', 'cpu')
+    getattr(PP, name)()
