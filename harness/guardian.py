@@ -46,9 +46,12 @@ class Reporter(object):
             return
         msg = json.dumps({'line': line, 'progress': {'done': list(done), 'running': running, 'wall_s': wall}}) + '\n'
         data = msg.encode()
-        while data:
-            n = os.write(self.fd, data)
-            data = data[n:]
+        try:
+            while data:
+                n = os.write(self.fd, data)
+                data = data[n:]
+        except OSError:                      # the guardian is gone (EPIPE): keep measuring, the worker prints the line itself at the end
+            self.fd = None
 
 
 def signal_name(rc):

@@ -33,6 +33,7 @@ namespace {
 
 constexpr float kTolDiffZero = 1e-10f;               // quant_functions.py:40, compared in fp32 as torch compares a float tensor with it
 constexpr int64_t kChunk = 1 << 16;                   // elements per work item of the flat (bucket_size=None) loops and reductions
+constexpr int64_t kParallelMin = 1 << 15;             // below this many elements a call runs on the calling thread
 
 inline void geometry(int64_t n, int64_t bucket, int64_t& nb, int64_t& row) {       // help_functions.py:67-94
     if (bucket <= 0 || n < bucket) { nb = 1; row = n; return; }
@@ -86,7 +87,7 @@ void whole_minmax(const float* x, int64_t n, const Prep& pp, float& a, float& b)
     const int64_t chunks = (n + kChunk - 1) / kChunk;
     std::vector<float> mns((size_t)chunks), mxs((size_t)chunks);
     std::vector<char> nans((size_t)chunks);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (chunks > 1)
     for (int64_t c = 0; c < chunks; ++c) {
         const int64_t lo = c * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
         float mn, mx;
@@ -190,14 +191,15 @@ void for_buckets(int64_t n, int64_t nb, int64_t row, Stats stats, Body body) {
         float a, b;
         stats(0, 0, n, a, b, true);
         const int64_t chunks = (n + kChunk - 1) / kChunk;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (chunks > 1)
         for (int64_t c = 0; c < chunks; ++c) {
             const int64_t lo = c * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
             body(0, lo, hi, a, b);
         }
         return;
     }
-#pragma omp parallel for schedule(static)
+    // (a parameter tensor of a few buckets -- biases, batch-norm vectors -- is not worth waking a thread team for)
+#pragma omp parallel for schedule(static) if (n >= kParallelMin)
     for (int64_t bk = 0; bk < nb; ++bk) {
         const int64_t lo = bk * row, hi = lo + row < n ? lo + row : n;
         float a, b;
@@ -248,7 +250,7 @@ int qd_mean_f32(const float* x, int64_t n, float* mean_out, void*, size_t, void*
     if (n <= 0 || !x || !mean_out) return QD_ERR_INVALID_ARGUMENT;
     const int64_t chunks = (n + kChunk - 1) / kChunk;
     std::vector<double> part((size_t)chunks);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (chunks > 1)
     for (int64_t c = 0; c < chunks; ++c) {
         const int64_t lo = c * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
         double acc = 0.0;
@@ -382,7 +384,7 @@ int qd_bucket_argminmax_f32(const float* x, int64_t n, int64_t bucket, const flo
     int64_t nb, row;
     geometry(n, bucket, nb, row);
     const Prep pp = make_prep(mean, clamp, max_element);
-#pragma omp parallel for schedule(static) if (nb > 1)
+#pragma omp parallel for schedule(static) if (nb > 1 && n >= kParallelMin)
     for (int64_t bk = 0; bk < nb; ++bk) {
         const int64_t lo = bk * row, hi = lo + row < n ? lo + row : n;
         float mn = pp(x[lo]), mx = mn;
@@ -467,7 +469,7 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     const int64_t chunks = (n + kChunk - 1) / kChunk;
     std::vector<double> part((size_t)(chunks > 0 ? chunks : 1) * (size_t)k, 0.0);
     int bad = 0;
-#pragma omp parallel for schedule(static) reduction(| : bad)
+#pragma omp parallel for schedule(static) reduction(| : bad) if (chunks > 1)
     for (int64_t c = 0; c < chunks; ++c) {
         const int64_t lo = c * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
         double* acc = part.data() + (size_t)c * (size_t)k;
@@ -499,7 +501,7 @@ int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64
     geometry(n, bucket, nb, row);
     const float sm1 = (float)(levels - 1);
     const Prep none = make_prep(nullptr, 0, 0.0f);
-#pragma omp parallel
+#pragma omp parallel if (n >= kParallelMin)
     {
         std::vector<float> qb((size_t)row);
 #pragma omp for schedule(static)
@@ -550,7 +552,7 @@ int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64
 // K8: 'truncated' STE (cnn_models/conv_forward_model.py:240-241,263-264)
 int qd_clamp_f32(float* w, int64_t n, float limit, void*) {
     if (n < 0 || (n > 0 && !w)) return QD_ERR_INVALID_ARGUMENT;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= kParallelMin)
     for (int64_t i = 0; i < n; ++i) {
         float v = w[i];
         v = v > limit ? limit : v;                                                  // (NaN stays NaN, as torch.clamp)
@@ -561,7 +563,7 @@ int qd_clamp_f32(float* w, int64_t n, float limit, void*) {
 }
 int qd_truncated_ste_f32(const float* w, float* grad, int64_t n, float limit, void*) {
     if (n < 0 || (n > 0 && (!w || !grad))) return QD_ERR_INVALID_ARGUMENT;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= kParallelMin)
     for (int64_t i = 0; i < n; ++i)
         if (std::fabs(w[i]) > limit) grad[i] = 0.0f;
     return 0;

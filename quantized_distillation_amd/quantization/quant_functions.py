@@ -403,7 +403,7 @@ def uniformQuantization(tensor, s, type_of_scaling='linear', stochastic_rounding
     place; ref: conv_forward_model.py:216-221) takes a path with the argument checks inlined --
     this function is called once per parameter tensor per step."""
     global _glue_uniform, _glue_uniform_common
-    if type(tensor) is torch.Tensor and not tensor.is_cuda:          # a CPU tensor: libqd_host.so (the tensor's device decides)
+    if isinstance(tensor, torch.Tensor) and not tensor.is_cuda:      # a CPU tensor: libqd_host.so (the tensor's device decides)
         return _uniform_host(tensor, s, type_of_scaling, stochastic_rounding, max_element, subtract_mean, bucket_size,
                              modify_in_place)
     if _glue_uniform is None:
