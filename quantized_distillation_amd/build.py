@@ -137,6 +137,7 @@ def build_glue(force=False, verbose=False):
 
 HOST_FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', '-fopenmp',
               '-ffp-contract=off', '-fno-fast-math',     # as the device build: every fp32 op rounded separately, no reassociation
+              '-fno-trapping-math', '-fno-math-errno',   # value-neutral: lets the compiler if-convert and vectorise the compare / select chains
               '-fvisibility=hidden',                      # only the extern "C" entry points leave the library ...
               '-Wl,-Bsymbolic-functions']                 # ... and its own calls to them never resolve into libqd_hip.so (same names)
 

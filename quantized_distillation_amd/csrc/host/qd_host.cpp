@@ -59,21 +59,10 @@ inline Prep make_prep(const float* mean, int clamp, float max_element) {
 }
 
 // min / max of prep(x[lo..hi)) with torch's NaN propagation (one NaN makes both NaN) -> alpha, beta (:85-99)
+static void span_minmax(const float* x, int64_t lo, int64_t hi, float mean, float me, float* mn_out, float* mx_out, int* nan_out);
 inline void range_minmax(const float* x, int64_t lo, int64_t hi, const Prep& pp, float& mn, float& mx, bool& nan) {
-    mn = std::numeric_limits<float>::infinity();
-    mx = -mn;
-    nan = false;
-    const float mean = pp.mean, me = pp.me;
     int nans = 0;
-#pragma omp simd reduction(min : mn) reduction(max : mx) reduction(| : nans)
-    for (int64_t i = lo; i < hi; ++i) {
-        float v = x[i] - mean;
-        v = v > me ? me : v;
-        v = v < -me ? -me : v;
-        nans |= (v != v) ? 1 : 0;
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
-    }
+    span_minmax(x, lo, hi, pp.mean, pp.me, &mn, &mx, &nans);
     nan = nans != 0;
 }
 inline void alpha_beta(float mn, float mx, bool nan, float& a, float& b) {
@@ -148,6 +137,57 @@ inline float qdq(float v, float a, float b, float sm1, float mean, float& level)
     y = y + mean;
     return y;
 }
+// ---- the four streaming loops of the per-step calls as free functions, compiled three times (function multi-versioning: the
+// dynamic linker picks the AVX-512 / AVX2 / baseline SSE2 clone for the CPU it runs on).  Same C source, same IEEE operations in
+// every clone -- vector width is the only difference (-ffp-contract=off: no clone fuses a multiply-add) -- so the results are the
+// same bits on every machine.
+#define QD_CLONES __attribute__((target_clones("avx512f", "avx2", "default"), noinline))
+
+QD_CLONES static void span_minmax(const float* x, int64_t lo, int64_t hi, float mean, float me, float* mn_out, float* mx_out, int* nan_out) {
+    float mn = std::numeric_limits<float>::infinity(), mx = -mn;
+    int nans = 0;
+#pragma omp simd reduction(min : mn) reduction(max : mx) reduction(| : nans)
+    for (int64_t i = lo; i < hi; ++i) {
+        float v = x[i] - mean;
+        v = v > me ? me : v;
+        v = v < -me ? -me : v;
+        nans |= (v != v) ? 1 : 0;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    *mn_out = mn; *mx_out = mx; *nan_out = nans;
+}
+// q may alias x exactly: element i is read before it is written, no dependence between iterations
+QD_CLONES static void span_qdq(const float* x, float* q, int64_t lo, int64_t hi, float a, float b, float sm1, float mean, float me) {
+#pragma omp simd
+    for (int64_t i = lo; i < hi; ++i) {
+        float v = x[i] - mean;
+        v = v > me ? me : v;
+        v = v < -me ? -me : v;
+        float lev;
+        q[i] = qdq(v, a, b, sm1, mean, lev);
+    }
+}
+QD_CLONES static void span_scale(const float* x, float* u, int64_t lo, int64_t hi, float a, float b, float mean, float me) {
+#pragma omp simd
+    for (int64_t i = lo; i < hi; ++i) {
+        float v = x[i] - mean;
+        v = v > me ? me : v;
+        v = v < -me ? -me : v;
+        v = v - b;                                                                  // :106-107
+        u[i] = v / a;
+    }
+}
+QD_CLONES static void span_inv(const float* u, float* y, int64_t lo, int64_t hi, float a, float b, float m) {
+#pragma omp simd
+    for (int64_t i = lo; i < hi; ++i) {
+        float r = u[i] * a;                                                         // :142-143, two ops
+        r = r + b;
+        r = r + m;                                                                  // :148
+        y[i] = r;
+    }
+}
+
 // stochastic variant (:174-187): floor + Bernoulli(frac)
 inline float qdq_stochastic(float v, float a, float b, float sm1, float mean, float rnd, float& level) {
     float u = v - b;
@@ -289,17 +329,8 @@ int qd_uniform_f32(const float* x, float* q, int64_t n, int64_t bucket, int leve
     };
     auto body = [&](int64_t, int64_t lo, int64_t hi, float a, float b) {
         if (!stochastic && !level_idx) {
-            // the per-step case: a branch-free loop the compiler vectorises (IEEE vector division; q may alias x exactly --
-            // element i is read before it is written, no dependence between iterations)
-            const float mean = pp.mean, me = pp.me;
-#pragma omp simd
-            for (int64_t i = lo; i < hi; ++i) {
-                float v = x[i] - mean;
-                v = v > me ? me : v;
-                v = v < -me ? -me : v;
-                float lev;
-                q[i] = qdq(v, a, b, sm1, mean, lev);
-            }
+            // the per-step case: a branch-free vector loop (IEEE vector division)
+            span_qdq(x, q, lo, hi, a, b, sm1, pp.mean, pp.me);
             return;
         }
         for (int64_t i = lo; i < hi; ++i) {
@@ -336,15 +367,7 @@ int qd_scale_down_f32(const float* x, float* u, int64_t n, int64_t bucket, float
         beta[bk] = b;
     };
     auto body = [&](int64_t, int64_t lo, int64_t hi, float a, float b) {
-        const float mean = pp.mean, me = pp.me;
-#pragma omp simd
-        for (int64_t i = lo; i < hi; ++i) {
-            float v = x[i] - mean;
-            v = v > me ? me : v;
-            v = v < -me ? -me : v;
-            v = v - b;                                                              // :106-107
-            u[i] = v / a;
-        }
+        span_scale(x, u, lo, hi, a, b, pp.mean, pp.me);
         if (hi == n && nb > 1) {                                                    // padding: the scaled last element (help_functions.py:76-86)
             const float last = u[n - 1];
             for (int64_t i = n; i < nb * row; ++i) u[i] = last;
@@ -364,13 +387,7 @@ int qd_inv_scale_f32(const float* u, float* y, int64_t n, int64_t bucket, const 
     const float m = mean ? *mean : 0.0f;
     auto stats = [&](int64_t bk, int64_t, int64_t, float& a, float& b, bool) { a = alpha[bk]; b = beta[bk]; };
     auto body = [&](int64_t, int64_t lo, int64_t hi, float a, float b) {
-#pragma omp simd
-        for (int64_t i = lo; i < hi; ++i) {
-            float r = u[i] * a;                                                     // :142-143, two ops
-            r = r + b;
-            r = r + m;                                                              // :148
-            y[i] = r;
-        }
+        span_inv(u, y, lo, hi, a, b, m);
     };
     for_buckets(n, nb, row, stats, body);
     return 0;
