@@ -289,7 +289,8 @@ class ScalingFunction(object):
             return self._scale_down_abs(tensor, n, nb, padded)
         in_place = self.modify_in_place and padded == n
         self._note_arg_source(tensor, overwritten=in_place)
-        out = tensor.view(-1) if in_place else torch.empty(padded, dtype=torch.float32, device=tensor.device)
+        out = tensor.view(-1) if in_place else (torch.empty(padded, dtype=torch.float32, device=tensor.device) if tensor.is_cuda
+                                                else _lib.fresh_host_output(padded, torch.float32))
         ab = self._alloc_alpha_beta(nb, tensor.device)
         clamp, me = self._clamp_args()
         if n > 0:
@@ -368,7 +369,7 @@ def _uniform_host(tensor, s, type_of_scaling, stochastic_rounding, max_element, 
     x, n, nb, row = sf._begin(tensor)                      # sizes, the mean if asked for
     sf.modify_in_place = True
     sf._note_arg_source(x, overwritten=bool(modify_in_place))      # the lazy arg indices: now, if x is about to be overwritten
-    q = x if modify_in_place else torch.empty_like(x)
+    q = x if modify_in_place else _lib.fresh_host_output(n, torch.float32, like=x)
     ab = sf._alloc_alpha_beta(nb, x.device)
     clamp, me = sf._clamp_args()
     if n > 0:
@@ -550,8 +551,8 @@ def _nearest(x, prescaled, points, assign_mode, n, bucket_size, alpha, beta, mea
     """(q [n], idx [n]) -- one K4/K5 launch through the native binding (allocation + stream + launch).  in_place: q is
     written over x (every kernel of the family loads a bucket before it stores it)."""
     if not x.is_cuda:                                   # a CPU tensor: the same entry point of libqd_host.so
-        q = x.view(-1)[0:n] if in_place else torch.empty(n, dtype=torch.float32)
-        idx = torch.empty(n, dtype=torch.int64 if idx_bytes == 8 else torch.uint8)
+        q = x.view(-1)[0:n] if in_place else _lib.fresh_host_output(n, torch.float32)
+        idx = _lib.fresh_host_output(n, torch.int64 if idx_bytes == 8 else torch.uint8)
         if n > 0:
             _lib.check(_lib.host().qd_nearest_point_f32(
                 x.data_ptr(), 1 if prescaled else 0, points.data_ptr(), points.numel(), assign_mode, q.data_ptr(), idx.data_ptr(),
