@@ -39,16 +39,36 @@ def main():
     if os.path.exists(prev):
         libs.insert(0, ('previous', prev))
     for model in models:
-        shapes = kernel_bench.model_shapes(model) if model != 'one64Mi' else [(1 << 26,)]
+        # diagnostic shape lists besides the two config models: one tensor; the WRN list without its 43 tensors below one tile
+        # (wrn_big); eight equal tensors of the same total (eq8); the WRN list with every tensor a view of ONE flat buffer per
+        # kind, 256-byte aligned slots, as the data-parallel harness lays its gradients out (wrn_flat)
+        base = model.replace('_flat', '').replace('_big', '')
+        if model == 'one64Mi':
+            shapes = [(1 << 26,)]
+        elif model == 'eq8':
+            shapes = [(82746890 // 8,)] * 8
+        else:
+            shapes = kernel_bench.model_shapes(base)
         ns = [int(np.prod(s)) for s in shapes]
+        if model.endswith('_big'):
+            ns = [n for n in ns if n >= 1024]
+        flat = model.endswith('_flat')
         tot = sum(ns)
         g = torch.Generator().manual_seed(0)
         nset = 64 if model == 'student' else 3
+        tot = sum(ns)
         for k in ks:
             sets = []
             for _ in range(nset):
-                grads = [torch.randn(n, generator=g).to(dev) for n in ns]
-                idx = [torch.randint(0, k, (n,), generator=g, dtype=torch.uint8).to(dev) for n in ns]
+                if flat:
+                    offs = np.cumsum([0] + [-(-n // 64) * 64 for n in ns])
+                    fg = torch.randn(int(offs[-1]), generator=g).to(dev)
+                    fi = torch.randint(0, k, (int(offs[-1]),), generator=g, dtype=torch.uint8).to(dev)
+                    grads = [fg[o:o + n] for o, n in zip(offs, ns)]
+                    idx = [fi[o:o + n] for o, n in zip(offs, ns)]
+                else:
+                    grads = [torch.randn(n, generator=g).to(dev) for n in ns]
+                    idx = [torch.randint(0, k, (n,), generator=g, dtype=torch.uint8).to(dev) for n in ns]
                 alpha = [(torch.rand(-(-n // 256) if n > 256 else 1, generator=g) + 0.5).to(dev) for n in ns]
                 sets.append((grads, idx, alpha))
             # float64 reference of set 0
