@@ -207,7 +207,8 @@ def supervise(worker_cmd, all_legs, rank=0, world=1, wall_limit_s=1500.0, max_re
         finish(runs[-1]['exit'] if runs else None)
     finally:
         for s, h in old.items():
-            signal.signal(s, h)
+            if h is not None:                # None: the previous handler was not installed from Python (a profiler's, a launcher's
+                signal.signal(s, h)          # C-level one -- rocprofv3 does that): nothing Python could put back, and nothing to undo
     if rank != 0:
         return 0
     return 0 if (state['line'] or {}).get('value') else 1

@@ -136,3 +136,31 @@ def test_bench_legs_and_budget_table_are_consistent():
     assert {'cifar_graph', 'rocprof', 'cpu_baseline', 'pcie_note', 'cpu_distill'} <= off       # N > 1: no capture next to live collectives
     assert 'cifar_graph' not in bench.disabled_legs(bench.parse_args(['--gpus', '8', '--graph-at-any-n']), 8)
     assert bench.disabled_legs(bench.parse_args([]), 1) == set()
+
+
+def test_a_signal_handler_installed_outside_python_does_not_break_the_guardian(tmp_path):
+    """Under rocprofv3 SIGTERM / SIGINT already carry a C-level handler when the interpreter starts (its preloaded tool library
+    installs them): signal.signal() then returns None as the previous handler, and putting None back raises TypeError -- which
+    made the guardian exit 1 AFTER printing the line, and at N > 1 made torchrun tear rank 0 down before it printed (found by
+    running bench.py under rocprofv3, tools/bench_under_rocprof.sh).  Reproduced with a preloaded library whose constructor
+    installs the handlers."""
+    import shutil
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        pytest.skip('no C compiler')
+    src = tmp_path / 'pre.c'
+    src.write_text('#include <signal.h>\nstatic void h(int s) { (void)s; }\n'
+                   '__attribute__((constructor)) static void init(void) { signal(SIGTERM, h); signal(SIGINT, h); }\n')
+    lib = tmp_path / 'libpre.so'
+    subprocess.check_call([cc, '-shared', '-fPIC', str(src), '-o', str(lib)])
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    e['LD_PRELOAD'] = str(lib)
+    probe = subprocess.run([sys.executable, '-c', 'import signal; print(signal.getsignal(signal.SIGTERM))'], env=e, stdout=subprocess.PIPE, text=True)
+    assert probe.stdout.strip() == 'None'                       # the situation: a handler Python did not install
+    p = subprocess.run([sys.executable, FAKE], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=e)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr[-1500:])
+    assert json.loads(lines[0])['value'] == 123.0
+    # ... and a dying worker is still handled under it
+    p = subprocess.run([sys.executable, FAKE, '--die-in', 'b'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=e)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])['bench_process']['restarts'] == 1
