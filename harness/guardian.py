@@ -97,6 +97,17 @@ def _read_snapshots(proc, rfd, state, wall_limit_s, t0, log):
             time.sleep(0.1)                       # the worker closed the pipe but is still running: wait for it
 
 
+def _die_with_parent():
+    """preexec of the worker: have the kernel send it SIGKILL when the guardian dies (prctl PR_SET_PDEATHSIG).  The worker runs
+    in its own session (so that the guardian can end the whole group: rocprofv3 children, data-loader processes); without this
+    a guardian that is SIGKILLed -- a driver's hard timeout -- would leave a worker behind that holds the GPU."""
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)        # 1 = PR_SET_PDEATHSIG
+    except Exception:                                        # noqa: BLE001 -- not Linux / no libc: nothing to set
+        pass
+
+
 def _kill_group(proc, log):
     for sig in (signal.SIGTERM, signal.SIGKILL):
         if proc.poll() is not None:
@@ -164,7 +175,8 @@ def supervise(worker_cmd, all_legs, rank=0, world=1, wall_limit_s=1500.0, max_re
             e[REPORT_FD_ENV] = str(wfd)
             # the worker's stdout is this process's stderr: RCCL banners, MIOpen chatter and stray prints can never
             # reach the stdout that carries the line
-            proc = subprocess.Popen(worker_cmd(extra), env=e, pass_fds=(wfd,), stdout=sys.stderr.fileno(), start_new_session=True)
+            proc = subprocess.Popen(worker_cmd(extra), env=e, pass_fds=(wfd,), stdout=sys.stderr.fileno(), start_new_session=True,
+                                    preexec_fn=_die_with_parent)
             os.close(wfd)
             current['proc'] = proc
             why = _read_snapshots(proc, rfd, state, wall_limit_s, t0, log)

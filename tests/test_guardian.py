@@ -164,3 +164,25 @@ def test_a_signal_handler_installed_outside_python_does_not_break_the_guardian(t
     # ... and a dying worker is still handled under it
     p = subprocess.run([sys.executable, FAKE, '--die-in', 'b'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=e)
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])['bench_process']['restarts'] == 1
+
+
+def test_a_sigkilled_guardian_takes_its_worker_with_it(tmp_path):
+    """A hard kill of the guardian (a driver's timeout) must not leave the measuring process behind on the GPU: the worker asks
+    the kernel to be killed with its parent (PR_SET_PDEATHSIG)."""
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.Popen([sys.executable, FAKE, '--die-in', 'c', '--how', 'hang'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+    time.sleep(3.0)
+    kids = subprocess.run(['pgrep', '-P', str(p.pid)], stdout=subprocess.PIPE, text=True).stdout.split()
+    assert len(kids) == 1, kids
+    p.kill()
+    p.wait(10)
+    deadline = time.time() + 10
+    while time.time() < deadline and os.path.exists('/proc/%s' % kids[0]):
+        try:
+            if open('/proc/%s/stat' % kids[0]).read().split()[2] == 'Z':      # reaped by init soon: gone for our purposes
+                break
+        except OSError:
+            break
+        time.sleep(0.2)
+    alive = os.path.exists('/proc/%s' % kids[0]) and open('/proc/%s/stat' % kids[0]).read().split()[2] != 'Z'
+    assert not alive, 'the worker survived its guardian'
