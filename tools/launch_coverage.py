@@ -101,11 +101,12 @@ def run(pytest_args):
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     out_dir = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
-    # (profiles/r05_launch_coverage.json was recorded with --ignore=tests/test_hip_bench_ranks.py
-    # --ignore=tests/test_hip_capture_watchdog.py: bench.py's guardian then tripped over the C-level signal handlers rocprofv3
-    # preloads -- fixed since (harness/guardian.py, tools/bench_under_rocprof.sh) -- and the two files launch no kernel that
-    # the others do not.  The capture tests stay out: their child processes abort on purpose.)
-    args = pytest_args or ['tests', '-q', '-m', 'gpu', '-x', '-p', 'no:cacheprovider', '--ignore=tests/test_hip_capture_watchdog.py']
+    # (the two files that test bench.py's PROCESS orchestration are left out: their workers abort on purpose, and a process that
+    # calls abort() under rocprofv3 does not die -- the profiler's own SIGABRT handling hangs it (measured: the abort-injection
+    # test of test_hip_bench_ranks.py sat there until its 900 s timeout).  They launch no kernel that the other files do not;
+    # bench.py as a whole under rocprofv3 is tools/bench_under_rocprof.sh.)
+    args = pytest_args or ['tests', '-q', '-m', 'gpu', '-x', '-p', 'no:cacheprovider',
+                           '--ignore=tests/test_hip_bench_ranks.py', '--ignore=tests/test_hip_capture_watchdog.py']
     with tempfile.TemporaryDirectory(dir='/tmp') as td:
         cmd = [exe, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', td, '-o', 'cov', '--', sys.executable, '-m', 'pytest'] + args
         env = dict(os.environ, TMPDIR='/tmp')
