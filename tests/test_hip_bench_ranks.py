@@ -23,7 +23,7 @@ def test_two_ranks_quick_run_end_to_end():
     cmd = launch.launcher_command(os.path.join(ROOT, 'bench.py'), 2, ['--gpus', '2', '--steps', '5', '--warmup', '2', '--quick', '--no-cpu-baseline',
                                                                        '--no-pmc', '--no-kernels', '--precondition-s', '0.05',
                                                                        '--skip-legs', 'diffquant_wrn,nmt_lstm_dp'])     # (all four legs: tools/gpu_session.sh ranks2)
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -80,8 +80,9 @@ def test_a_leg_that_aborts_the_worker_costs_that_leg_only():
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--quick', '--no-pmc',
-                        '--precondition-s', '0.05', '--skip-legs', 'diffquant_wrn,nmt_lstm_dp,imagenet_resnet18k_dp,kernels'],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                        '--precondition-s', '0.05', '--skip-legs', 'diffquant_wrn,nmt_lstm_dp,imagenet_resnet18k_dp,kernels',
+                        '--deadline-s', '300'],          # (the guardian's own wall limit: a hang costs minutes, not the suite)
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
