@@ -49,9 +49,11 @@ def test_long_thread_local_capture_with_an_incomplete_allreduce_listed_by_the_wa
 def test_the_same_capture_in_global_mode_is_round_4s_crash():
     """... and in torch's default 'global' mode the same situation IS the crash that cost round 4 its driver measurement: the
     watchdog thread's event query is refused ("operation not permitted when stream is capturing"), its exception ends the
-    process with SIGABRT.  Kept as a test so that the hazard stays documented by something that runs; if a later torch / HIP
-    makes global mode survive this, the assertion below is what to delete."""
+    process with SIGABRT (4 of 4 runs on four boxes in round 5).  Kept as a test so that the hazard stays documented by something
+    that runs; on a stack where global mode survives it skips, saying so."""
     p = run_worker('--long-capture', '0.5', '--mode', 'global')
+    if p.returncode == 0 and 'LONG_CAPTURE_OK' in p.stdout:
+        pytest.skip('a global-mode capture survived the watchdog on this stack: the hazard this documents is gone here')
     assert p.returncode != 0 and 'LONG_CAPTURE_OK' not in p.stdout
     assert 'stream is capturing' in p.stderr and 'watchdog' in p.stderr, p.stderr[-2000:]
 
