@@ -86,7 +86,7 @@ inline void mark_written(const at::Tensor& t) {
 void require_device_f32(const at::Tensor& t, const char* what) {
     if (!t.is_cuda())
         throw std::runtime_error(std::string("quantized_distillation_amd: ") + what +
-                                 " must live on a HIP device (got " + t.device().str() + "); this package has no CPU path");
+                                 " must live on a HIP device (got " + t.device().str() + "); this binding has no CPU path (CPU tensors are served by libqd_host.so through the Python API)");
     if (t.scalar_type() != at::kFloat) {
         PyErr_Format(PyExc_TypeError, "%s must be float32 (the reference path is fp32-only), got %s", what,
                      c10::toString(t.scalar_type()));
