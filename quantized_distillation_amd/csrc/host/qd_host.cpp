@@ -35,6 +35,19 @@ constexpr float kTolDiffZero = 1e-10f;               // quant_functions.py:40, c
 constexpr int64_t kChunk = 1 << 16;                   // elements per work item of the flat (bucket_size=None) loops and reductions
 constexpr int64_t kParallelMin = 1 << 15;             // below this many elements a call runs on the calling thread
 
+// threads worth waking for n elements: one per 64 Ki elements, at most what OpenMP would use (a 64-thread host quantizing an
+// 800 K-element layer needs a dozen of them, not the whole team)
+inline int threads_for(int64_t n) {
+#ifdef _OPENMP
+    const int64_t want = n / kChunk + 1;
+    const int have = omp_get_max_threads();
+    return (int)(want < have ? want : have);
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 inline void geometry(int64_t n, int64_t bucket, int64_t& nb, int64_t& row) {       // help_functions.py:67-94
     if (bucket <= 0 || n < bucket) { nb = 1; row = n; return; }
     row = bucket;
@@ -231,7 +244,7 @@ void for_buckets(int64_t n, int64_t nb, int64_t row, Stats stats, Body body) {
         float a, b;
         stats(0, 0, n, a, b, true);
         const int64_t chunks = (n + kChunk - 1) / kChunk;
-#pragma omp parallel for schedule(static) if (chunks > 1)
+#pragma omp parallel for schedule(static) if (chunks > 1) num_threads(threads_for(n))
         for (int64_t c = 0; c < chunks; ++c) {
             const int64_t lo = c * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
             body(0, lo, hi, a, b);
@@ -239,7 +252,7 @@ void for_buckets(int64_t n, int64_t nb, int64_t row, Stats stats, Body body) {
         return;
     }
     // (a parameter tensor of a few buckets -- biases, batch-norm vectors -- is not worth waking a thread team for)
-#pragma omp parallel for schedule(static) if (n >= kParallelMin)
+#pragma omp parallel for schedule(static) if (n >= kParallelMin) num_threads(threads_for(n))
     for (int64_t bk = 0; bk < nb; ++bk) {
         const int64_t lo = bk * row, hi = lo + row < n ? lo + row : n;
         float a, b;
@@ -486,7 +499,7 @@ int qd_point_grad_f32(const float* g, const void* idx, int idx_bytes, const floa
     const int64_t chunks = (n + kChunk - 1) / kChunk;
     std::vector<double> part((size_t)(chunks > 0 ? chunks : 1) * (size_t)k, 0.0);
     int bad = 0;
-#pragma omp parallel for schedule(static) reduction(| : bad) if (chunks > 1)
+#pragma omp parallel for schedule(static) reduction(| : bad) if (chunks > 1) num_threads(threads_for(n))
     for (int64_t c = 0; c < chunks; ++c) {
         const int64_t lo = c * kChunk, hi = lo + kChunk < n ? lo + kChunk : n;
         double* acc = part.data() + (size_t)c * (size_t)k;
@@ -518,7 +531,7 @@ int qd_ste_bucket_backward_f32(const float* x, const float* g, float* out, int64
     geometry(n, bucket, nb, row);
     const float sm1 = (float)(levels - 1);
     const Prep none = make_prep(nullptr, 0, 0.0f);
-#pragma omp parallel if (n >= kParallelMin)
+#pragma omp parallel if (n >= kParallelMin) num_threads(threads_for(n))
     {
         std::vector<float> qb((size_t)row);
 #pragma omp for schedule(static)
