@@ -18,8 +18,8 @@ once, when the worker has ended -- however it ended.  Round 4's driver run was l
 in an optional leg 50 s after the headline had been measured; now a dying leg costs that leg: the
 guardian records it, starts a fresh worker for the legs that are left (N = 1) and prints the line.
 
-Order of the legs (N = 1: the whole default run takes ~95 s on a fresh box, 41 s of which are MIOpen's first-use search for the
-WideResNet-16-22 convolution shapes inside the diffquant_wrn leg -- its `warmup_s`):
+Order of the legs (N = 1: the whole default run takes ~65 s on a fresh box; the steps/sec legs run with MIOpen's FAST find mode,
+harness/legs.py miopen_env_defaults -- the default mode's first-use search for the WideResNet shapes alone took 45 s):
   headline        the timed region of the contract (+ the kernel's HIP-event time -> roofline)
   rocprof         the same kernel under rocprofv3 in child processes: --kernel-trace duration, PMC HBM traffic
   cpu_baseline    the REFERENCE's own uniformQuantization on the host cores, same workload; checker of the GPU result
@@ -39,17 +39,15 @@ uses the ranks it was given.  At N = 1 a single-rank RCCL group is created when 
 steps/sec leg starts (not before: the headline needs none), so the gradient all-reduce of those
 legs really runs through RCCL on a one-GPU box.
 
-Rank 0's guardian prints ONE JSON line.  Besides the contract fields it carries
-  roofline      achieved algorithmic GB/s of the dominant kernel (8 B/element: 4 read + 4 written,
-                SURVEY.md 8d) from HIP-event timing of the timed region, against the 8 TB/s peak;
-                roofline.kernels: the same figure for every other kernel on the path.  The driver's
-                record keeps only the SCALARS of this object, so every row is also there as a short
-                string (k01, k02, ...), and so are the steps/sec and data-parallel figures of the
-                `distill` object (steps_cfg*, dp_cfg*) and the wall seconds of every leg
-  cpu_baseline  the REFERENCE's own uniformQuantization (staged bytecode of
-                /root/reference/quantization, oracle/ref_stage.py) timed on the host cores of this
-                box on the same workload, with the two ports (C/OpenMP, torch ops) next to it
-  bench_process what the guardian saw: worker exits, restarts, legs lost with their worker.
+Rank 0's guardian prints ONE JSON line of at most 4096 bytes (harness/report.py) -- the contract fields, `config`,
+  roofline      achieved algorithmic GB/s of the dominant kernel (8 B/element: 4 read + 4 written) from
+                HIP-event timing of the timed region against the 8 TB/s peak, the kernel's rocprofv3 duration and PMC
+                traffic measured in the same run, the worst other kernel row
+  cpu_baseline  the REFERENCE's own uniformQuantization (staged bytecode of /root/reference/quantization,
+                oracle/ref_stage.py) timed on the host cores of this box on the same workload
+  steps_per_sec / dp   one number per BASELINE config, and the data-parallel figures of each
+-- and writes the full record (every kernel row, the legs' sub-records, sample descriptions, what the guardian saw of
+its workers) to bench_detail.json next to this file (--detail PATH) and to stderr.
 """
 import argparse
 import json
@@ -64,8 +62,8 @@ if ROOT not in sys.path:
 # the default run, in order; everything after 'cifar_student' is optional (wall budget)
 LEGS = ['headline', 'rocprof', 'cpu_baseline', 'kernels', 'cifar_student',
         'cifar_graph', 'pcie_note', 'diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp', 'cpu_distill']
-OPTIONAL = {'cifar_graph': 4, 'pcie_note': 1, 'diffquant_wrn': 50, 'imagenet_resnet18k_dp': 4, 'nmt_lstm_dp': 9, 'cpu_distill': 12}
-#            ^ seconds a leg is expected to take on an MI355X box (profiles/r05_bench*.json legs_wall_s): it starts only if that fits the budget
+OPTIONAL = {'cifar_graph': 4, 'pcie_note': 1, 'diffquant_wrn': 12, 'imagenet_resnet18k_dp': 4, 'nmt_lstm_dp': 9, 'cpu_distill': 12}
+#            ^ seconds a leg is expected to take on an MI355X box (profiles/r06_bench*.json legs_wall_s): it starts only if that fits the budget
 DISTILL_LEGS = ('cifar_student', 'cifar_graph', 'diffquant_wrn', 'imagenet_resnet18k_dp', 'nmt_lstm_dp')
 
 
@@ -81,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-dp-configs', action='store_true', help='skip the ImageNet-shaped and seq2seq steps/sec legs')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 child processes (kernel duration + PMC HBM traffic of the headline kernel)')
-    ap.add_argument('--budget-s', type=float, default=150.0,
+    ap.add_argument('--budget-s', type=float, default=100.0,
                     help='wall budget of the run: an OPTIONAL leg starts only if its expected duration still fits (0: no limit)')
     ap.add_argument('--deadline-s', type=float, default=1500.0,
                     help='after this many seconds the guardian ends the worker and prints the line with what has been measured so far')
@@ -89,6 +87,7 @@ def parse_args(argv=None):
     ap.add_argument('--graph-at-any-n', action='store_true', help='run the hipGraph replay leg at N > 1 too (default: N = 1 only)')
     ap.add_argument('--cpu-distill-steps', type=int, default=60, help='steps of the configs[0] CPU leg (200 = the whole synthetic epoch)')
     ap.add_argument('--quick', action='store_true', help='short steps/sec legs (a few steps, two repetitions): for exercising the flow, not for numbers')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'bench_detail.json'), help='where rank 0 writes the full record (stdout carries the compact line)')
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)          # the measuring process (started by the guardian)
     ap.add_argument('--resume', default=None, help=argparse.SUPPRESS)                 # guardian -> fresh worker: the line so far + the legs done
     ap.add_argument('--pmc-slice', action='store_true', help=argparse.SUPPRESS)       # child mode of measure_pmc_traffic()
@@ -145,7 +144,8 @@ def guardian_main(args, argv):
 
     def worker_cmd(extra):
         return [sys.executable, os.path.abspath(__file__), '--worker'] + list(argv) + list(extra)
-    return guardian.supervise(worker_cmd, [x for x in LEGS if x not in off], rank=rank, world=world, wall_limit_s=args.deadline_s)
+    return guardian.supervise(worker_cmd, [x for x in LEGS if x not in off], rank=rank, world=world, wall_limit_s=args.deadline_s,
+                              detail_path=args.detail)
 
 
 # ---------------------------------------------------------------------------------------------- worker
@@ -156,6 +156,7 @@ def worker_main(args):
     from harness import guardian, launch, legs
     t_start = time.time()
     legs.rccl_env_defaults()                 # (before the first HIP call: the runtime reads HSA_ENABLE_IPC_MODE_LEGACY when it starts)
+    miopen_find_mode = legs.miopen_env_defaults()
     reporter = guardian.Reporter()
     N_ELEM, LEVELS, BUCKET, N_ROTATE = bl.N_ELEM, bl.LEVELS, bl.BUCKET, bl.N_ROTATE
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -226,46 +227,8 @@ def worker_main(args):
     runner = legs.LegRunner()                # the per-leg agreement runs over its own gloo group (harness/legs.py)
 
     def snapshot(running=None):
-        mirror_scalars(line)
-        reporter.send(line, done, running, round(time.time() - t_start, 1))
-
-    def mirror_scalars(line):
-        """The scalars the driver's record keeps (it drops nested objects): steps/sec + data-parallel figures, the kernel rows,
-        the legs' wall seconds."""
-        r = line.get('roofline')
-        if not isinstance(r, dict):
-            return
-        d = line.get('distill') or {}
-        cs = d.get('cifar_student') or {}
-        if 'multi' in cs:
-            r['steps_cfg1'] = ' | '.join('%s %.1f (%.1f-%.1f)' % (m, cs[m]['steps_per_sec'], cs[m]['steps_per_sec_min'], cs[m]['steps_per_sec_max'])
-                                         for m in ('multi', 'per_tensor') if 'steps_per_sec' in (cs.get(m) or {}))[:118]
-            r['dp_cfg1'] = bl.flat_dp(cs.get('dp'))
-        elif cs:
-            r['steps_cfg1'] = bl.flat_dp(cs)
-        cg = d.get('cifar_graph') or {}
-        if cg:
-            r['steps_cfg1_graph'] = (' | '.join('%s %.1f (%.1f-%.1f)' % (m, cg[m]['steps_per_sec'], cg[m]['steps_per_sec_min'], cg[m]['steps_per_sec_max'])
-                                                for m in ('multi_graph', 'multi') if 'steps_per_sec' in (cg.get(m) or {}))
-                                     or str(cg.get('error') or cg.get('skipped')))[:118]
-        for key, tag in (('diffquant_wrn', 'dp_cfg2_wrn_diffquant'), ('imagenet_resnet18k_dp', 'dp_cfg3_imagenet'), ('nmt_lstm_dp', 'dp_cfg4_nmt')):
-            if key in d:
-                r[tag] = bl.flat_dp(d[key])
-        if isinstance(r.get('kernels'), list):
-            from harness.kernel_bench import flat_row
-            for i, row in enumerate(r['kernels']):
-                r['k%02d' % (i + 1)] = flat_row(row)
-        c0 = (line.get('cpu_baseline') or {}).get('distill') if isinstance(line.get('cpu_baseline'), dict) else line.get('cpu_distill')
-        if isinstance(c0, dict) and 'steps_per_sec' in c0:
-            pr = c0.get('product_on_cpu_tensors') or {}
-            r['steps_cfg0_cpu'] = ('reference quantizer %.2f steps/s (quantize %.1f ms/step, %d threads)' % (
-                c0['steps_per_sec'], c0['quantize_ms_per_step'], c0.get('threads', 0)) + (
-                ' | this package on CPU tensors %.2f (quantize %.1f ms/step), same weights: %s' % (
-                    pr['steps_per_sec'], pr['quantize_ms_per_step'], pr.get('weights_after_training_bit_identical_to_the_reference_run'))
-                if 'steps_per_sec' in pr else ''))[:236]
-        r['legs_wall_s'] = ' '.join('%s=%s' % (k, v) for k, v in wall.items())[:236]
-        r['wall_s'] = round(time.time() - t_start, 1)
-        line['roofline'] = line.pop('roofline')                    # last: the driver keeps the tail of the line
+        line['wall_s'] = round(time.time() - t_start, 1)
+        reporter.send(line, done, running, line['wall_s'])
 
     def want(name):
         return name not in done and name not in off
@@ -434,8 +397,7 @@ def worker_main(args):
             'value': round(bytes_per_launch * args.steps * n_gpus / elapsed / 1e9, 2),
             'ms_per_step': round(elapsed * 1e3 / args.steps, 5),
             'config': {
-                'workload': 'uniformQuantization(x, s=16, bucket_size=256), x = randn(64Mi) fp32 per GPU (BASELINE configs[1] hot path, '
-                            'headline size)',
+                'workload': 'uniformQuantization(x, s=16, bucket_size=256) on x = randn(64Mi) fp32 per GPU: 4-bit quantize-dequantize',
                 'call': 'quantization.uniformQuantization(x, s=16, type_of_scaling="linear", bucket_size=256), deterministic rounding, '
                         'through the public API (result allocation + one launch through the C ABI)',
                 'n_elements_per_gpu': N_ELEM, 'levels': LEVELS, 'bucket_size': BUCKET,
@@ -445,7 +407,7 @@ def worker_main(args):
             'cpu_baseline': None, 'distill': None,
             'parity_bit_exact_vs_oracle': None, 'parity_bit_exact_vs_reference': None,
             'rccl_world_size': group['world'], 'rccl_error': group['error'], 'collective_backend': backend,
-            'device': torch.cuda.get_device_name(dev),
+            'device': torch.cuda.get_device_name(dev), 'miopen_find_mode': miopen_find_mode,
             'roofline': roofline,
         })
         wall['headline'] = round(time.time() - t_leg, 1)
@@ -544,7 +506,10 @@ def worker_main(args):
 
     snapshot()
     if reporter.fd is None and rank == 0:                          # `bench.py --worker` run by hand: no guardian to print the line
-        print(json.dumps(line), flush=True)
+        from harness import report
+        if report.write_detail(args.detail, line):
+            line['detail'] = os.path.basename(args.detail)
+        print(report.fit(report.compact(line)), flush=True)
     runner.barrier()                                               # (gloo: works whatever the legs left behind)
     if dist.is_initialized():
         if runner.broken is None:

@@ -9,9 +9,10 @@ line belongs to this one, which imports neither torch nor HIP and therefore cann
          ^                                           |
          +------- snapshots over a pipe -------------+   one JSON object per line: {"line": {...}, "progress": {...}}
 
-The worker sends a snapshot of the line whenever a leg finishes (and a progress marker before a leg starts).  The
-guardian keeps the last complete one and prints it -- exactly once, as the last thing on stdout -- when the worker
-ends, however it ends: exit 0, an exception, a signal, the wall limit.  If the worker died inside a leg and this is a
+The worker sends a snapshot of its record whenever a leg finishes (and a progress marker before a leg starts).  The
+guardian keeps the last complete one and, when the worker ends -- however it ends: exit 0, an exception, a signal, the
+wall limit -- writes the full record to `detail_path` and to stderr and prints its COMPACT form (harness/report.py:
+at most 4096 bytes) exactly once, as the only thing on stdout.  If the worker died inside a leg and this is a
 one-rank run, the guardian starts a fresh worker for the legs that are left (the dead leg is recorded as such and not
 retried), so one bad leg costs that leg only.  At N > 1 the ranks cannot be restarted one by one; the line then holds
 what rank 0 had measured.
@@ -28,6 +29,8 @@ import subprocess
 import sys
 import tempfile
 import time
+
+from . import report
 
 REPORT_FD_ENV = 'QD_BENCH_REPORT_FD'
 
@@ -122,8 +125,11 @@ def _kill_group(proc, log):
             log('guardian: worker group did not end on %s' % sig.name)
 
 
-def supervise(worker_cmd, all_legs, rank=0, world=1, wall_limit_s=1500.0, max_restarts=2, out=None, log=None, env=None):
+def supervise(worker_cmd, all_legs, rank=0, world=1, wall_limit_s=1500.0, max_restarts=2, out=None, log=None, env=None,
+              detail_path=None, compact=report.compact):
     """Run `worker_cmd(extra_args) -> argv` under supervision; print the line (rank 0) and return the exit code.
+
+    Rank 0 writes the full record to `detail_path` (if given) and to stderr, and prints report.fit(compact(record)) on `out`.
 
     worker_cmd(extra) must return the argv of a worker that understands
         --resume FILE     JSON {"line": ..., "done": [...], "dead": {leg: reason}}: continue from there
@@ -152,9 +158,10 @@ def supervise(worker_cmd, all_legs, rank=0, world=1, wall_limit_s=1500.0, max_re
             if line.get('value') is None and 'error' not in line:
                 line['error'] = 'the worker ended before the headline was measured (%s); see stderr' % (code_hint,)
             line['bench_process'] = info
-            if 'roofline' in line:                       # the driver keeps the tail of the line: roofline stays last
-                line['roofline'] = line.pop('roofline')
-            out.write(json.dumps(line) + '\n')
+            if detail_path and report.write_detail(detail_path, line, log):
+                line['detail'] = os.path.basename(detail_path)
+            log('bench record (full): ' + json.dumps(line))
+            out.write(report.fit(compact(line)) + '\n')
             out.flush()
 
     def on_signal(signum, _frame):

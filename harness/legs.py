@@ -53,6 +53,19 @@ def rccl_env_defaults(env=None):
     return env
 
 
+def miopen_env_defaults(env=None):
+    """MIOpen's FAST find mode for the steps/sec legs (before the first convolution: MIOpen reads the variable once).  The
+    default hybrid mode benchmarks every applicable solver the first time it sees a shape its find-db does not hold: 45 s for
+    the WideResNet-16-22 shapes of configs[2] on a fresh box, inside the one command the driver times, on every rank.  FAST
+    takes the find-db entry when there is one and the immediate-mode heuristic otherwise: 2.9 s, at 8.0 instead of 8.4
+    steps/s on configs[2] and within 1 % on configs[3] (profiles/r06_miopen_find_mode.txt).  The convolutions are the
+    callers' work, not the path measured here; the quantizer phases of those legs are timed on their own and do not change.
+    Returns the mode in force (a value exported by the user wins)."""
+    env = os.environ if env is None else env
+    env.setdefault('MIOPEN_FIND_MODE', '2')
+    return env['MIOPEN_FIND_MODE']
+
+
 def data_timeout(seconds=None):
     """Timeout of the data-path group's collectives (QD_BENCH_DATA_TIMEOUT_S overrides the default: the tests use a short one)."""
     if seconds is None:

@@ -3,7 +3,9 @@
     python fake_bench.py [--die-in LEG --how abort|exit|hang|raise] [--dist]     the guardian
     python fake_bench.py --worker ...                                            the worker it starts
 
-Legs: headline, a, b, c.  --dist: the worker joins the gloo group of its torchrun environment (short timeout), every leg but
+Legs: headline, a, b, c.  The guardian prints the COMPACT line (harness/report.py) and writes the full record to --detail.
+--fat: the headline leg fills the record with a real full-size one (tests/golden/bench_record_full.json: round 5's 24 KB
+record, the one the driver could not parse when it was printed whole).  --dist: the worker joins the gloo group of its torchrun environment (short timeout), every leg but
 the headline holds an all-reduce and ends with the LegRunner agreement, and --die-rank says which rank dies.
 """
 import argparse
@@ -32,6 +34,8 @@ def parse(argv):
     ap.add_argument('--deadline-s', type=float, default=60.0)
     ap.add_argument('--world', type=int, default=None, help='pretend world size (guardian restart policy) without a launcher')
     ap.add_argument('--rank', type=int, default=None)
+    ap.add_argument('--detail', default=None)
+    ap.add_argument('--fat', action='store_true')
     return ap.parse_args(argv)
 
 
@@ -67,8 +71,13 @@ def worker(args):
         if args.die_in == leg and rank == args.die_rank and not (resume and leg in resume['done']):
             die(args.how)
         if leg == 'headline':
-            line['value'] = 123.0
-            line['roofline'] = {'frac': 0.8}
+            if args.fat:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_record_full.json')) as f:
+                    line.update(json.load(f))
+                line['n_gpus'] = int(os.environ.get('WORLD_SIZE', '1'))
+            else:
+                line['value'] = 123.0
+                line['roofline'] = {'frac': 0.8}
         elif runner is not None:
             def body():
                 t = torch.ones(2)
@@ -80,7 +89,8 @@ def worker(args):
         done.append(leg)
         rep.send(line, done, running=None)
     if rep.fd is None:
-        print(json.dumps(line), flush=True)
+        from harness import report
+        print(report.fit(report.compact(line)), flush=True)
     if runner is not None:
         runner.barrier()
         os._exit(0)
@@ -97,7 +107,7 @@ def main():
 
     def cmd(extra):
         return [sys.executable, os.path.abspath(__file__), '--worker'] + argv + list(extra)
-    return guardian.supervise(cmd, LEGS, rank=rank, world=world, wall_limit_s=args.deadline_s)
+    return guardian.supervise(cmd, LEGS, rank=rank, world=world, wall_limit_s=args.deadline_s, detail_path=args.detail)
 
 
 if __name__ == '__main__':

@@ -9,57 +9,121 @@ import os
 import signal
 import subprocess
 import sys
+import tempfile
 import time
 
 import pytest
 
-from harness import launch
+from harness import launch, report
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 FAKE = os.path.join(HERE, 'fake_bench.py')
 
 
+def detail_file():
+    fd, path = tempfile.mkstemp(suffix='.json', prefix='qd_fake_detail_')
+    os.close(fd)
+    os.unlink(path)
+    return path
+
+
+def read_detail(path):
+    """The full record the guardian wrote next to the compact line (None if it wrote none)."""
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return None
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+def check_stdout_line(text):
+    """What the driver does with stdout: the last line of its tail must be ONE complete JSON object."""
+    assert len(text.encode()) <= report.LINE_LIMIT, len(text)
+    return json.loads(text)
+
+
 def run(*argv, timeout=120, env=None):
+    """-> (process, stdout lines, the full record from the detail file).  stdout carries the compact line only."""
     e = {k: v for k, v in (env or os.environ).items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    p = subprocess.run([sys.executable, FAKE] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=e)
+    path = detail_file()
+    p = subprocess.run([sys.executable, FAKE, '--detail', path] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout, env=e)
     lines = [l for l in p.stdout.splitlines() if l.strip()]
-    return p, lines
+    for l in lines:
+        check_stdout_line(l)
+    return p, lines, read_detail(path)
 
 
 def test_clean_run_prints_exactly_one_line():
-    p, lines = run()
+    p, lines, full = run()
     assert p.returncode == 0, p.stderr
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d['value'] == 123.0 and d['a'] == d['b'] == d['c'] == 'ok'
-    assert d['bench_process']['restarts'] == 0 and d['bench_process']['workers'] == [{'exit': 0, 'legs_done': 4}]
-    assert list(d)[-1] == 'roofline'                     # the driver keeps the tail of the line
+    assert d['value'] == 123.0 and d['roofline']['frac'] == 0.8 and d['detail'].endswith('.json')
+    assert d['bench_process'] == {'workers': 1, 'restarts': 0, 'wall_s': d['bench_process']['wall_s'], 'last_exit': 0}
+    assert full['value'] == 123.0 and full['a'] == full['b'] == full['c'] == 'ok'
+    assert full['bench_process']['restarts'] == 0 and full['bench_process']['workers'] == [{'exit': 0, 'legs_done': 4}]
+    assert 'bench record (full): ' in p.stderr                        # ... and the full record is on stderr too, never on stdout
+
+
+def test_a_full_size_record_is_printed_as_a_line_the_driver_can_parse():
+    """Round 5's defect: the 24 KB record was printed whole and the driver's record of stdout holds less than that.  The same
+    record through the guardian: one line of at most 4096 bytes that parses from the last 6000 bytes of stdout and carries
+    what the contract asks of `roofline` and `cpu_baseline`; the whole record is in the detail file."""
+    p, lines, full = run('--fat')
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
+    assert len(lines[0].encode()) <= 4096
+    d = json.loads(p.stdout[-6000:].splitlines()[-1])
+    for key in report.CONTRACT:
+        assert key in d, key
+    assert d['metric'] == 'quantize_dequantize_GBps_64M_fp32_4bit' and d['dtype'] == 'f32' and d['value'] > 1000
+    r = d['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'avg_launch_us', 'rocprof_kernel_avg_us', 'rocprof_frac',
+                'traffic_over_algorithmic', 'algorithmic_bytes_per_launch', 'worst_kernel', 'worst_kernel_frac'):
+        assert key in r, key
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] > r['algorithmic_bytes_per_launch'] * 0.98
+    c = d['cpu_baseline']
+    for key in ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model', 'os_cpu_count', 'threads'):
+        assert key in c, key
+    assert c['kind'] == 'reference' and c['value'] > 1 and len(c['sample']) <= 160
+    assert len(d['config']['workload']) <= 120 and d['config']['n_elements_per_gpu'] == 1 << 26
+    assert d['parity_bit_exact_vs_reference'] is True and d['rccl_world_size'] == 1
+    assert set(d['steps_per_sec']) >= {'cfg0_cpu_reference_quantizer', 'cfg1_cifar_student', 'cfg2_diffquant_wrn', 'cfg3_imagenet_resnet18k', 'cfg4_nmt_lstm'}
+    assert all(isinstance(v, float) for v in d['steps_per_sec'].values())
+    assert set(d['dp']) == {'cfg1', 'cfg2', 'cfg3', 'cfg4'} and all('dp_efficiency' in v for v in d['dp'].values())
+    assert 'dropped_to_fit' not in d
+    assert len(full['roofline']['kernels']) == 28 and len(json.dumps(full)) > 20000       # nothing lost: the detail file has it all
 
 
 @pytest.mark.parametrize('how,shown', [('abort', 'SIGABRT'), ('exit', 7), ('raise', 1)])
 def test_a_worker_that_dies_in_a_leg_costs_that_leg_only(how, shown):
-    p, lines = run('--die-in', 'b', '--how', how)
+    p, lines, full = run('--die-in', 'b', '--how', how)
     assert p.returncode == 0, p.stderr
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d['value'] == 123.0 and d['a'] == 'ok' and d['c'] == 'ok' and 'b' not in d
-    bp = d['bench_process']
+    assert d['value'] == 123.0
+    assert d['bench_process']['restarts'] == 1 and d['bench_process']['workers'] == 2 and d['bench_process']['legs_lost'] == ['b']
+    assert full['a'] == 'ok' and full['c'] == 'ok' and 'b' not in full
+    bp = full['bench_process']
     assert bp['restarts'] == 1 and len(bp['workers']) == 2
     assert bp['workers'][0]['exit'] == shown and bp['workers'][0]['during'] == 'b' and bp['workers'][1]['exit'] == 0
     assert 'b' in bp['legs_lost_with_their_worker'] and str(shown) in bp['legs_lost_with_their_worker']['b']
-    assert d['lost'] == bp['legs_lost_with_their_worker']       # the fresh worker was told
+    assert full['lost'] == bp['legs_lost_with_their_worker']       # the fresh worker was told
 
 
 def test_the_last_leg_dying_needs_no_restart():
-    p, lines = run('--die-in', 'c')
+    p, lines, full = run('--die-in', 'c')
     assert p.returncode == 0 and len(lines) == 1
-    d = json.loads(lines[0])
-    assert d['a'] == d['b'] == 'ok' and 'c' not in d and d['bench_process']['restarts'] == 0
+    assert json.loads(lines[0])['bench_process']['last_exit'] == 'SIGABRT'
+    assert full['a'] == full['b'] == 'ok' and 'c' not in full and full['bench_process']['restarts'] == 0
 
 
 def test_dying_before_the_headline_is_an_error_line_and_a_nonzero_exit():
-    p, lines = run('--die-in', 'headline')
+    p, lines, full = run('--die-in', 'headline')
     assert p.returncode == 1 and len(lines) == 1
     d = json.loads(lines[0])
     assert d['value'] is None and 'SIGABRT' in d['error']
@@ -67,34 +131,37 @@ def test_dying_before_the_headline_is_an_error_line_and_a_nonzero_exit():
 
 def test_a_hanging_leg_is_ended_at_the_wall_limit_with_the_line_intact():
     t0 = time.time()
-    p, lines = run('--die-in', 'b', '--how', 'hang', '--deadline-s', '3')
+    p, lines, full = run('--die-in', 'b', '--how', 'hang', '--deadline-s', '3')
     assert time.time() - t0 < 30
     assert p.returncode == 0 and len(lines) == 1, (p.stdout, p.stderr)
     d = json.loads(lines[0])
-    assert d['value'] == 123.0 and d['a'] == 'ok' and 'b' not in d and 'wall limit' in d['error']
-    assert d['bench_process']['workers'][-1]['during'] == 'b'
+    assert d['value'] == 123.0 and 'wall limit' in d['error']
+    assert full['a'] == 'ok' and 'b' not in full and full['bench_process']['workers'][-1]['during'] == 'b'
 
 
 def test_multi_rank_runs_are_not_restarted_and_other_ranks_stay_silent():
-    p, lines = run('--die-in', 'b', '--world', '2', '--rank', '0')
+    p, lines, full = run('--die-in', 'b', '--world', '2', '--rank', '0')
     assert p.returncode == 0 and len(lines) == 1
-    d = json.loads(lines[0])
-    assert d['a'] == 'ok' and 'c' not in d and d['bench_process']['restarts'] == 0
-    p, lines = run('--die-in', 'b', '--world', '2', '--rank', '1')
-    assert p.returncode == 0 and lines == []               # a non-zero exit would make torchrun tear rank 0 down before it prints
+    assert json.loads(lines[0])['bench_process']['restarts'] == 0
+    assert full['a'] == 'ok' and 'c' not in full
+    p, lines, full = run('--die-in', 'b', '--world', '2', '--rank', '1')
+    assert p.returncode == 0 and lines == [] and full is None      # a non-zero exit would make torchrun tear rank 0 down before it prints
 
 
 def test_sigterm_to_the_guardian_prints_the_line_and_ends_the_worker():
     e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    p = subprocess.Popen([sys.executable, FAKE, '--die-in', 'c', '--how', 'hang'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+    path = detail_file()
+    p = subprocess.Popen([sys.executable, FAKE, '--detail', path, '--die-in', 'c', '--how', 'hang'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, env=e)
     time.sleep(3.0)                                        # headline, a, b are done by now; c hangs
     p.send_signal(signal.SIGTERM)
     out, err = p.communicate(timeout=30)
     lines = [l for l in out.splitlines() if l.strip()]
     assert p.returncode == 0 and len(lines) == 1, (out, err)
-    d = json.loads(lines[0])
-    assert d['value'] == 123.0 and d['b'] == 'ok' and 'c' not in d
-    assert 'SIGTERM' in d['bench_process']['workers'][-1]['exit']
+    d = check_stdout_line(lines[0])
+    full = read_detail(path)
+    assert d['value'] == 123.0 and 'SIGTERM' in d['bench_process']['last_exit']
+    assert full['b'] == 'ok' and 'c' not in full and 'SIGTERM' in full['bench_process']['workers'][-1]['exit']
 
 
 def test_rank_1_killed_with_sigabrt_mid_leg_rank_0_still_prints_the_headline():
@@ -103,16 +170,37 @@ def test_rank_1_killed_with_sigabrt_mid_leg_rank_0_still_prints_the_headline():
     120 s in bench.py), the leg is recorded as failed, the later collective-bearing legs are skipped, and rank 0's guardian
     prints ONE line with the headline; the launcher exits 0."""
     t0 = time.time()
-    rc, out = launch.run_ranks(FAKE, 2, ['--dist', '--die-in', 'a', '--die-rank', '1'], timeout=240, capture=True)
+    path = detail_file()
+    rc, out = launch.run_ranks(FAKE, 2, ['--detail', path, '--dist', '--die-in', 'a', '--die-rank', '1'], timeout=240, capture=True)
     took = time.time() - t0
     lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
     assert rc == 0, out[-3000:]
     assert len(lines) == 1, out[-3000:]
-    d = json.loads(lines[0])
+    d = check_stdout_line(lines[0])
+    full = read_detail(path)
     assert d['value'] == 123.0 and d['n_gpus'] == 2
-    assert 'error' in d['a'] and 1 in d['a']['failed_ranks']
-    assert 'skipped' in d['b'] and 'skipped' in d['c']
+    assert 'error' in full['a'] and 1 in full['a']['failed_ranks']
+    assert 'skipped' in full['b'] and 'skipped' in full['c']
     assert took < 120, took
+
+
+def test_two_gloo_ranks_full_size_record_rank_0_prints_the_compact_line():
+    """The same at two ranks under torch.distributed.run: rank 0's line is the only JSON on the launcher's stdout, it has the
+    same shape as at N = 1 and n_gpus = 2; rank 1 prints nothing."""
+    path = detail_file()
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    p = subprocess.run(launch.launcher_command(FAKE, 2, ['--detail', path, '--dist', '--fat']), env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = check_stdout_line(p.stdout[-6000:].splitlines()[-1])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['roofline']['frac'] > 0.5 and d['cpu_baseline']['value'] > 1
+    one = report.compact(json.load(open(os.path.join(HERE, 'golden', 'bench_record_full.json'))))
+    assert set(one) - {'bench_process', 'detail'} <= set(d)             # the shape of the line does not depend on N
+    assert read_detail(path)['n_gpus'] == 2
 
 
 def test_bench_py_guardian_never_imports_torch():
@@ -160,7 +248,7 @@ def test_a_signal_handler_installed_outside_python_does_not_break_the_guardian(t
     p = subprocess.run([sys.executable, FAKE], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=e)
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stderr[-1500:])
-    assert json.loads(lines[0])['value'] == 123.0
+    assert check_stdout_line(lines[0])['value'] == 123.0
     # ... and a dying worker is still handled under it
     p = subprocess.run([sys.executable, FAKE, '--die-in', 'b'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=e)
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])['bench_process']['restarts'] == 1
