@@ -96,6 +96,8 @@ def cpu_baseline(x_host, q_gpu, alpha_gpu, budget_s=2.0, with_ports=True):
                       'quantization.uniformQuantization (bytecode of /root/reference/quantization staged by oracle/ref_stage.py), '
                       'torch %s CPU ops, torch.set_num_threads(%d) = best of the thread counts tried; min %.4f s, median %.4f s'
                       % (best[3], n, LEVELS, BUCKET, torch.__version__, best[0], best[1], best[2]),
+            'sample_short': "%d runs of the full 64Mi-element call by the reference's own uniformQuantization (oracle/_ref), torch CPU ops, "
+                            'best of %s threads; min %.4f s' % (best[3], '/'.join(str(c) for c in counts), best[1]),
             'threads_tried': per_threads,
             'reference_sources_sha256': (ref_stage.manifest() or {}).get('files'),
         })

@@ -199,6 +199,16 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
     del pks, pk
     add('LVH level histogram of x, s=16 b256', 'k_level_hist_vec<16,4>+k_hist_fold', lambda i: codec.level_histogram(xs[i % R], 16, 256), 4, N,
         note='levels counted in the kernel that computes them: 4 B read, nothing written')
+    # the Huffman accounting's per-tensor step (help_functions.py:215-223): re-scale the QUANTIZED tensor, digitize, count
+    import quantization.help_functions as qhf
+    qs = [quantization.uniformQuantization(x, 16, bucket_size=256)[0] for x in xs]
+    e16 = torch.from_numpy(qhf._digitize_edges(16, 1e-5)).to(dev)
+    sf = quantization.ScalingFunction('linear', False, False, bucket_size=256)
+    add('HUF re-scale + digitize + count of q, s=16 b256 (one pass)', 'k_scale_digitize_hist_vec<16,4>+k_hist_fold',
+        lambda i: qhf._fused_rescale_counts(qs[i % R], sf, 16, e16), 4, N, note='4 B read, nothing written')
+    add('HUF the two-kernel form it replaces (scale_down, then digitize + count)', 'k_bucket_vec<1,16,4,1>+k_hist_sym<0>+k_hist_fold',
+        lambda i: qhf._device_counts('digitize', sf.scale_down(qs[i % R]).view(-1), 16, e16), 12, N, note='4 r + 4 w, then 4 r')
+    del qs
     live[:] = [None] * R
     del xs
     NH = 1 << hist_log2n

@@ -55,9 +55,9 @@ extern "C" {
 /* Library identification: ABI version (bumped on every change of an entry point's meaning or signature) and target arch.
  * History: 1 = rounds 1-3; 2 = qd_nearest_point_f32 accepts q == NULL (indices only), qd_uniform_f32 accepts q == NULL with
  * level_idx (levels only), qd_selftest_div_invariant, qd_digitize_histogram_f32 / qd_histogram_i64 / qd_level_histogram_f32
- * added, 4-byte data alignment.
+ * added, 4-byte data alignment; 3 = qd_scale_digitize_histogram_f32 added.
  * The Python binding and _qd_glue.so compare the version THEY were built for with the library's. */
-#define QD_ABI_VERSION 2
+#define QD_ABI_VERSION 3
 int qd_abi_version(void);
 const char* qd_target_arch(void);
 const char* qd_error_string(int code);
@@ -272,6 +272,14 @@ int qd_digitize_histogram_f32(const float* v, int64_t n, const double* edges, in
                               size_t workspace_bytes, void* stream);
 int qd_histogram_i64(const int64_t* idx, int64_t n, int k, uint64_t* hist, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* qd_scale_digitize_histogram_f32: the re-scale and the digitize + count of :215-223 in ONE pass over the quantized tensor q
+ * (4 B read per element; the two-call form -- qd_scale_down_f32, then qd_digitize_histogram_f32 over its output -- moves 12):
+ * hist[c] = #{ i : #{ j < m : edges[j] <= (double)u[i] } == c } with u = ScalingFunction('linear', bucket_size=bucket)
+ * .scale_down(q), i.e. per bucket (q - min) / (max - min or 1), bit-identical to qd_scale_down_f32's output.  For the plain
+ * configuration only (no mean subtraction, no max_element), bucket in {64 ... 2048}, q 16-byte aligned: QD_ERR_UNSUPPORTED
+ * otherwise, and the caller takes the two-call form.  edges, hist, workspace as for qd_digitize_histogram_f32. */
+int qd_scale_digitize_histogram_f32(const float* q, int64_t n, int64_t bucket, const double* edges, int m, uint64_t* hist,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- order statistics for initialize_quantization_points (quantization/help_functions.py:140-154: the reference
  * copies the scaled tensor to the host and calls np.percentile(a, linspace(0, 100, k)), which needs the two

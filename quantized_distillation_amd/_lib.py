@@ -21,7 +21,8 @@ HOST_LIB_PATH = os.path.join(_HERE, 'libqd_host.so')      # the same entry point
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 
-ABI_VERSION = 2                # QD_ABI_VERSION of include/qd_hip.h this file mirrors (tests/test_abi.py compares the two)
+QD_ERR_UNSUPPORTED = -3            # include/qd_hip.h
+ABI_VERSION = 3                # QD_ABI_VERSION of include/qd_hip.h this file mirrors (tests/test_abi.py compares the two)
 
 _lib = None
 _lock = threading.Lock()
@@ -89,6 +90,7 @@ SIGNATURES = {
     'qd_level_histogram_f32': (c_int, [c_f, i64, i64, c_int, c_p, c_p, c_size, c_p]),
     'qd_digitize_histogram_f32': (c_int, [c_f, i64, c_p, c_int, c_p, c_p, c_size, c_p]),
     'qd_histogram_i64': (c_int, [c_p, i64, c_int, c_p, c_p, c_size, c_p]),
+    'qd_scale_digitize_histogram_f32': (c_int, [c_f, i64, i64, c_p, c_int, c_p, c_p, c_size, c_p]),
     'qd_order_stats_workspace_bytes': (ctypes.c_size_t, [c_int]),
     'qd_order_stats_f32': (c_int, [c_p, i64, c_p, c_int, c_p, c_p, ctypes.c_size_t, c_p]),
     'qd_selftest_div_invariant': (c_int, [u64, i64, c_int, c_p, c_p]),

@@ -356,44 +356,92 @@ __global__ __launch_bounds__(256) void k_hist_fold(const unsigned long long* par
 // Per-block totals go to partial[row][block]; k_hist_fold sums them.
 enum { SRC_DIGITIZE = 0, SRC_I64 = 1 };
 
-__device__ __forceinline__ uint32_t digitize_count(const double* edges, int m, double e0, double inv, float v) {
+// np.digitize compares the float32 data, promoted to float64, with float64 edges.  Promotion is exact and monotonic, so
+//     edges[j] <= (double)v   <=>   v >= thr[j],   thr[j] = the smallest float32 whose promotion is >= edges[j]
+// and the whole search runs in float32 against a table every block derives from the edges once: no float64 arithmetic per
+// element (the float64 form bounded both digitizing kernels by VALU, not by HBM).  The table holds PAIRS,
+//     P[i] = (T[i], T[i + 1]),  T[0] = -inf, T[i] = thr[i - 1], T[m + 1] = +inf,   i = 0 .. m
+// so that one 8-byte LDS read decides whether a candidate count c is the answer: T[c] <= v < T[c + 1].
+__device__ __forceinline__ float digitize_threshold(double e) {
+    float f = (float)e;                                     // round to nearest; then up if that fell below e
+    if ((double)f < e) f = __uint_as_float(f == 0.0f ? 1u : (f > 0.0f ? __float_as_uint(f) + 1u : __float_as_uint(f) - 1u));
+    return f;                                               // (f = -inf < e gives -FLT_MAX; e above FLT_MAX gives +inf)
+}
+__device__ __forceinline__ void digitize_table(float2* P, const double* edges_g, int m) {   // all 256 threads; caller syncs
+    for (int i = threadIdx.x; i <= m; i += 256) {
+        const float lo = i == 0 ? -INFINITY : digitize_threshold(edges_g[i - 1]);
+        const float hi = i == m ? INFINITY : digitize_threshold(edges_g[i]);
+        P[i] = make_float2(lo, hi);
+    }
+}
+struct DigitizeGuess { float inv, off, top; };
+__device__ __forceinline__ DigitizeGuess digitize_guess(const float2* P, int m) {           // after the table is complete
+    DigitizeGuess G;
+    const float t0 = P[0].y;                                // thr[0]
+    const float span = P[m].x - t0;                         // thr[m - 1] - thr[0]
+    G.inv = (m > 1 && span > 0.0f && span < INFINITY) ? (float)(m - 1) / span : 0.0f;
+    G.off = 1.0f - t0 * G.inv;                              // candidate count = trunc((v - thr[0]) inv + 1), clamped to [0, m]
+    G.top = (float)m;
+    return G;
+}
+// Per element on the common path: one FMA, one median, one conversion, one 8-byte LDS read, two compares.  (The digitizing
+// kernels are bound by VALU issue and LDS latency, not by HBM, at 4 B per element.)
+__device__ __forceinline__ int digitize_candidate(const DigitizeGuess& G, float v) {
+    return (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(v, G.inv, G.off), 0.0f, G.top);      // in [0, m] for every v (NaN -> 0)
+}
+__device__ __noinline__ uint32_t digitize_walk(const float2* P, int m, float v, int c) {    // the rare path: kept out of line
     if (v != v) return (uint32_t)m;                        // NaN sorts last (numpy's searchsorted)
-    const double x = (double)v;
-    // candidate from the mean spacing (exact for evenly spaced edges up to rounding), then walked to the exact place:
-    // g = largest index with edges[g] <= x, or -1
-    const double t = (x - e0) * inv;
-    int g = t < 0.0 ? -1 : (t >= (double)(m - 1) ? m - 1 : (int)t);
-    while (g + 1 < m && edges[g + 1] <= x) ++g;
-    while (g >= 0 && edges[g] > x) --g;
-    return (uint32_t)(g + 1);
+    while (c < m && P[c].y <= v) ++c;
+    while (c > 0 && P[c].x > v) --c;
+    return (uint32_t)c;
+}
+__device__ __forceinline__ uint32_t digitize_count(const float2* P, int m, const DigitizeGuess& G, float v) {
+    // candidate from the mean spacing -- the answer right away for evenly spaced edges, which is what the caller has --
+    // checked with one LDS read, walked to the exact place when it is not.  A NaN fails the check whatever the candidate is.
+    const int c = digitize_candidate(G, v);
+    const float2 p = P[c];
+    if (__builtin_expect(!(p.x <= v && v < p.y), 0)) return digitize_walk(P, m, v, c);
+    return (uint32_t)c;
+}
+// N elements at once: all candidates, all table reads, ONE branch for the lot (element by element, every check waits for
+// its own LDS read and costs a branch: 60 instead of 4x us per 64 Mi elements).
+template <int N>
+__device__ __forceinline__ void digitize_many(const float2* P, int m, const DigitizeGuess& G, const float (&v)[N], uint32_t (&c)[N]) {
+    float2 p[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[k] = (uint32_t)digitize_candidate(G, v[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[k] = P[c[k]];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) bad |= !(p[k].x <= v[k] && v[k] < p[k].y);
+    if (__builtin_expect(bad, 0)) {
+#pragma unroll 1
+        for (int k = 0; k < N; ++k) c[k] = digitize_walk(P, m, v[k], (int)c[k]);
+    }
 }
 
 template <int SRC>
 __global__ __launch_bounds__(256) void k_hist_sym(const void* data, int64_t n, int nrows, const double* edges_g, int m,
                                                   unsigned long long* partial /* [nrows][gridDim.x] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hist_lds[];
-    double* edges = (double*)hist_lds;                                        // [m] (SRC_DIGITIZE), 8-byte aligned
-    uint32_t* cnt = (uint32_t*)(hist_lds + (SRC == SRC_DIGITIZE ? (size_t)((m + 1) & ~1) * sizeof(double) : 0));   // [nrows][32]
+    float2* P = (float2*)hist_lds;                                            // [m + 1] (SRC_DIGITIZE): digitize_table
+    uint32_t* cnt = (uint32_t*)(hist_lds + (SRC == SRC_DIGITIZE ? (size_t)(m + 1) * sizeof(float2) : 0));   // [nrows][32]
     typedef typename std::conditional<SRC == SRC_DIGITIZE, float, long long>::type T;
     constexpr int E = 16 / (int)sizeof(T);                                    // symbols per 16-byte load
     const T* src = (const T*)data;
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * 256;
     for (int j = threadIdx.x; j < nrows * 32; j += 256) cnt[j] = 0;
-    if (SRC == SRC_DIGITIZE)
-        for (int j = threadIdx.x; j < m; j += 256) edges[j] = edges_g[j];
+    if (SRC == SRC_DIGITIZE) digitize_table(P, edges_g, m);
     __syncthreads();
-    double e0 = 0.0, inv = 0.0;
-    if (SRC == SRC_DIGITIZE) {
-        e0 = edges[0];
-        const double span = edges[m - 1] - e0;
-        inv = (m > 1 && span > 0.0) ? (double)(m - 1) / span : 0.0;
-    }
+    DigitizeGuess G = {0.0f, 0.0f, 0.0f};
+    if (SRC == SRC_DIGITIZE) G = digitize_guess(P, m);
     uint32_t* col = cnt + (threadIdx.x & 31);
     const uint32_t last = (uint32_t)(nrows - 1);
     auto bump = [&](T v) {
         uint32_t sy;
-        if constexpr (SRC == SRC_DIGITIZE) sy = digitize_count(edges, m, e0, inv, v);
+        if constexpr (SRC == SRC_DIGITIZE) sy = digitize_count(P, m, G, v);
         else sy = (v < 0 || v >= (long long)last) ? last : (uint32_t)v;
         __hip_atomic_fetch_add(col + (sy < last ? sy : last) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -409,10 +457,23 @@ __global__ __launch_bounds__(256) void k_hist_sym(const void* data, int64_t n, i
         vecT w[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(body + i + (int64_t)u * nth);
+        if constexpr (SRC == SRC_DIGITIZE) {
+            float v[U * E];
+            uint32_t sy[U * E];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int c = 0; c < E; ++c) bump(w[u][c]);
+                for (int c = 0; c < E; ++c) v[u * E + c] = w[u][c];
+            digitize_many<U * E>(P, m, G, v, sy);
+#pragma unroll
+            for (int k = 0; k < U * E; ++k)
+                __hip_atomic_fetch_add(col + sy[k] * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < E; ++c) bump(w[u][c]);
+        }
     }
     for (; i < nvec; i += nth) {
         const vecT w = __builtin_nontemporal_load(body + i);
@@ -510,6 +571,95 @@ __global__ __launch_bounds__(256) void k_level_hist_vec(const float* x, int64_t 
     }
     __syncthreads();
     for (int j = threadIdx.x; j < levels; j += 256) {
+        unsigned long long total = 0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) total += cnt[j * 32 + ((c + j) & 31)];
+        partial[(size_t)j * gridDim.x + blockIdx.x] = total;
+    }
+}
+
+// The Huffman accounting's re-scale + digitize + count in ONE pass (ref: quantization/help_functions.py:215-223): for every
+// bucket of the QUANTIZED tensor q, u = (q - min) / (max - min) exactly as scale_down computes it (alpha_beta + the IEEE
+// quotient; the bucket-invariant form where scale_fast_ok proves it equal), c = #{ j < m : edges[j] <= (double)u } as
+// np.digitize does (digitize_count: in float32 against the promoted thresholds, exactly), counted in a [m + 1][32] LDS table.  4 B read per element, nothing written but the counters -- the
+// two-kernel form (qd_scale_down_f32, then qd_digitize_histogram_f32 over its output) moves 12.  Same loop shape as
+// k_level_hist_vec; the short last bucket is done by block 0's first wave (scale_down pads it with its last element, which
+// changes neither the minimum nor the maximum, and the padding is not counted: :216 cuts it off).
+template <int LPB, int V>
+__global__ __launch_bounds__(256) void k_scale_digitize_hist_vec(const float* q, int64_t nvec, int64_t n, const double* edges_g, int m,
+                                                                 unsigned long long* partial /* [m + 1][gridDim.x] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hist_lds[];
+    float2* P = (float2*)hist_lds;                                            // [m + 1]: digitize_table
+    uint32_t* cnt = (uint32_t*)(hist_lds + (size_t)(m + 1) * sizeof(float2));  // [m + 1][32]
+    constexpr int BPW = 64 / LPB;
+    constexpr int ROW = LPB * V * 4;
+    const int nrows = m + 1;
+    for (int j = threadIdx.x; j < nrows * 32; j += 256) cnt[j] = 0;
+    digitize_table(P, edges_g, m);
+    __syncthreads();
+    const DigitizeGuess G = digitize_guess(P, m);
+    uint32_t* col = cnt + (threadIdx.x & 31);
+    auto bump = [&](float u) {
+        const uint32_t c = digitize_count(P, m, G, u);
+        __hip_atomic_fetch_add(col + c * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPB, l = lane % LPB;
+    const int64_t wave = uniform_wave_index();
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ntiles = (nvec + BPW - 1) / BPW;
+    for (int64_t t = wave; t < ntiles; t += nwaves) {
+        const int64_t bkt = t * BPW + sub;
+        if (bkt >= nvec) continue;
+        const int64_t el0 = bkt * ROW + (int64_t)l * 4;
+        f4 v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = __builtin_nontemporal_load((const f4*)(q + el0) + j * LPB);
+        float mn = pmin4(v[0]), mx = pmax4(v[0]);                          // NaN-propagating, as torch's min / max
+#pragma unroll
+        for (int j = 1; j < V; ++j) { mn = pmin(mn, pmin4(v[j])); mx = pmax(mx, pmax4(v[j])); }
+        if (LPB == 16) { mn = row16_min(mn); mx = row16_max(mx); } else { mn = wave_min(mn); mx = wave_max(mx); }
+        float a, b;
+        alpha_beta(mn, mx, a, b);
+        unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            key = min(key, min(scale_numerator_key(v[j].x, b), scale_numerator_key(v[j].y, b)));
+            key = min(key, min(scale_numerator_key(v[j].z, b), scale_numerator_key(v[j].w, b)));
+        }
+        float u[V * 4];
+        if (!__any(!scale_fast_ok(a, key))) {                               // wave-uniform choice, as in the scale_down kernel
+            const float ry = 1.0f / a;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                u[4 * j + 0] = div_alpha<true>(v[j].x - b, a, ry); u[4 * j + 1] = div_alpha<true>(v[j].y - b, a, ry);
+                u[4 * j + 2] = div_alpha<true>(v[j].z - b, a, ry); u[4 * j + 3] = div_alpha<true>(v[j].w - b, a, ry);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                u[4 * j + 0] = (v[j].x - b) / a; u[4 * j + 1] = (v[j].y - b) / a;
+                u[4 * j + 2] = (v[j].z - b) / a; u[4 * j + 3] = (v[j].w - b) / a;
+            }
+        }
+        uint32_t c[V * 4];
+        digitize_many<V * 4>(P, m, G, u, c);
+#pragma unroll
+        for (int k = 0; k < V * 4; ++k) __hip_atomic_fetch_add(col + c[k] * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64 && nvec * ROW < n) {           // the short last bucket [nvec * ROW, n)
+        const int64_t lo = nvec * ROW;
+        float mn = INFINITY, mx = -INFINITY;
+        bool nan = false;
+        for (int64_t i = lo + lane; i < n; i += 64) { const float x = q[i]; mn = fminf(mn, x); mx = fmaxf(mx, x); nan |= (x != x); }
+        mn = wave_min(mn); mx = wave_max(mx);
+        if (group_any<64>(nan)) { mn = NAN; mx = NAN; }
+        float a, b;
+        alpha_beta(mn, mx, a, b);
+        for (int64_t i = lo + lane; i < n; i += 64) bump((q[i] - b) / a);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nrows; j += 256) {
         unsigned long long total = 0;
 #pragma unroll 8
         for (int c = 0; c < 32; ++c) total += cnt[j * 32 + ((c + j) & 31)];
@@ -682,7 +832,7 @@ int launch_hist_sym(const void* data, int64_t n, int nrows, const double* edges,
     const size_t room = workspace_bytes / ((size_t)nrows * sizeof(unsigned long long));
     if ((size_t)blocks > room) blocks = (int)room;
     if (blocks < 1) return QD_ERR_WORKSPACE_TOO_SMALL;
-    const size_t lds = (size_t)nrows * 32 * sizeof(uint32_t) + (SRC == SRC_DIGITIZE ? (size_t)((m + 1) & ~1) * sizeof(double) : 0);
+    const size_t lds = (size_t)nrows * 32 * sizeof(uint32_t) + (SRC == SRC_DIGITIZE ? (size_t)(m + 1) * sizeof(float2) : 0);
     const int64_t slice = (int64_t)blocks << 31;               // a uint32 counter holds what ONE block counts in one launch
     const size_t esz = SRC == SRC_DIGITIZE ? sizeof(float) : sizeof(long long);
     for (int64_t off = 0; off < n; off += slice) {
@@ -734,6 +884,45 @@ int qd_level_histogram_f32(const float* x, int64_t n, int64_t bucket, int levels
         default: QD_LH(64, 8) break;
     }
 #undef QD_LH
+    return (int)hipGetLastError();
+}
+
+int qd_scale_digitize_histogram_f32(const float* q, int64_t n, int64_t bucket, const double* edges, int m, uint64_t* hist,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || m < 1 || m > 256 || !edges || !hist || (n > 0 && !q) || (((uintptr_t)edges) & 7)) return QD_ERR_INVALID_ARGUMENT;
+    if (bucket != 64 && bucket != 128 && bucket != 256 && bucket != 512 && bucket != 1024 && bucket != 2048) return QD_ERR_UNSUPPORTED;
+    if (((uintptr_t)q) & 15) return QD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nrows = m + 1;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_zero_u64, dim3(1), dim3(256), 0, st, (unsigned long long*)hist, nrows);
+        return (int)hipGetLastError();
+    }
+    if (!workspace || (((uintptr_t)workspace) & 7)) return QD_ERR_WORKSPACE_TOO_SMALL;
+    const int64_t nfull = n / bucket;
+    const size_t lds = (size_t)nrows * 32 * sizeof(uint32_t) + (size_t)(m + 1) * sizeof(float2);
+#define QD_SDH(LPB, V)                                                                                                  \
+    {                                                                                                                   \
+        const int64_t tiles = (nfull + (64 / LPB) - 1) / (64 / LPB);                                                    \
+        int blocks = blocks_for(tiles > 0 ? tiles : 1, 4, device_cus() * 8);                                            \
+        const size_t room = workspace_bytes / ((size_t)nrows * sizeof(unsigned long long));                             \
+        if ((size_t)blocks > room) blocks = (int)room;                                                                  \
+        if (blocks < 1) return QD_ERR_WORKSPACE_TOO_SMALL;                                                              \
+        if (n > ((int64_t)blocks << 31)) return QD_ERR_UNSUPPORTED;        /* a uint32 counter per block and row */      \
+        hipLaunchKernelGGL((k_scale_digitize_hist_vec<LPB, V>), dim3(blocks), dim3(256), lds, st, q, nfull, n, edges, m, \
+                           (unsigned long long*)workspace);                                                             \
+        hipLaunchKernelGGL(k_hist_fold, dim3(nrows), dim3(256), 0, st, (const unsigned long long*)workspace, blocks,    \
+                           (unsigned long long*)hist, 0);                                                               \
+    }
+    switch (bucket) {
+        case 64: QD_SDH(16, 1) break;
+        case 128: QD_SDH(16, 2) break;
+        case 256: QD_SDH(16, 4) break;
+        case 512: QD_SDH(64, 2) break;
+        case 1024: QD_SDH(64, 4) break;
+        default: QD_SDH(64, 8) break;
+    }
+#undef QD_SDH
     return (int)hipGetLastError();
 }
 

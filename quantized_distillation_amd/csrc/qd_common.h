@@ -240,7 +240,7 @@ __device__ __forceinline__ void alpha_beta(float mn, float mx, float& a, float& 
 // below 2^-100 with alpha >= 2^-60 gives u < 2^-40, whose level is 0 whatever its last bit is -- so the form is used
 // where only the LEVEL of u is consumed (quantize-dequantize, deterministic or stochastic) without looking at the
 // numerators; scale_down, which returns u itself, uses it in the buckets whose nonzero numerators are all at least
-// max(2^-100, alpha 2^-120) -- a NORMAL quotient; a denormal one can differ in its last bit (qd_transform.h scale_fast_ok) --
+// max(2^-100, alpha 2^-120) -- a NORMAL quotient; a denormal one can differ in its last bit (scale_fast_ok below) --
 // and never where u is compared with points.  Buckets outside the range (incl. inf / NaN alpha) take the IEEE path.
 __device__ __forceinline__ bool fastdiv_ok(float a) { return a >= 0x1p-60f && a <= 0x1p100f; }   // false for NaN
 template <bool FAST>
@@ -251,6 +251,19 @@ __device__ __forceinline__ float div_alpha(float n, float a, float y) {
         return __builtin_fmaf(r, y, q);
     }
     return n / a;
+}
+
+// scale_down RETURNS u, so the bucket-invariant division form (qd_common.h) may replace the IEEE division only in a bucket
+// whose alpha is in the proven range AND whose numerators v - beta are all 0 or at least max(2^-100, alpha 2^-120): below
+// 2^-100 the remainder underflows, and a DENORMAL quotient can differ in its last bit (exact-arithmetic restatement,
+// tools/div_invariant_check.py: 3 of 3518 such pairs; 0 of 33824 with small normal quotients; family 5 of the device self
+// test).  One unsigned minimum per element decides it: bits(n) - 1 wraps 0 to the top, and n >= 0 (beta is the bucket's
+// minimum; a NaN anywhere makes alpha NaN, which fastdiv_ok refuses).  Almost every bucket of real data passes; one that
+// does not takes the IEEE form as before.
+__device__ __forceinline__ unsigned scale_numerator_key(float v, float b) { return __float_as_uint(v - b) - 1u; }
+__device__ __forceinline__ bool scale_fast_ok(float a, unsigned min_key) {
+    const float thr = fmaxf(0x1p-100f, a * 0x1p-120f);
+    return fastdiv_ok(a) && min_key >= __float_as_uint(thr) - 1u;
 }
 
 // ---- the k-level quantize-dequantize of one element (quant_functions.py:106-107,189-191,142-148)

@@ -266,19 +266,6 @@ __device__ __forceinline__ int assign_point(const PointStore& T, int k, int mode
     return i;
 }
 
-// scale_down RETURNS u, so the bucket-invariant division form (qd_common.h) may replace the IEEE division only in a bucket
-// whose alpha is in the proven range AND whose numerators v - beta are all 0 or at least max(2^-100, alpha 2^-120): below
-// 2^-100 the remainder underflows, and a DENORMAL quotient can differ in its last bit (exact-arithmetic restatement,
-// tools/div_invariant_check.py: 3 of 3518 such pairs; 0 of 33824 with small normal quotients; family 5 of the device self
-// test).  One unsigned minimum per element decides it: bits(n) - 1 wraps 0 to the top, and n >= 0 (beta is the bucket's
-// minimum; a NaN anywhere makes alpha NaN, which fastdiv_ok refuses).  Almost every bucket of real data passes; one that
-// does not takes the IEEE form as before.
-__device__ __forceinline__ unsigned scale_numerator_key(float v, float b) { return __float_as_uint(v - b) - 1u; }
-__device__ __forceinline__ bool scale_fast_ok(float a, unsigned min_key) {
-    const float thr = fmaxf(0x1p-100f, a * 0x1p-120f);
-    return fastdiv_ok(a) && min_key >= __float_as_uint(thr) - 1u;
-}
-
 // ---- per-element transform shared by every bucket kernel -----------------------------------
 // v: prepared value (mean subtracted, clamped) -- or u itself when prescaled.
 // e: global element index (for the side outputs and the random stream).

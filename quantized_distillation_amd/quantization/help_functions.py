@@ -233,6 +233,37 @@ def _device_counts(kind, values, nsym, edges_dev=None):
     return hist
 
 
+INDEX_RETAIN_BYTES = 1 << 30            # int64 indices awaiting their counters' trip to the host, per device
+FUSED_DIGITIZE_BUCKETS = (64, 128, 256, 512, 1024, 2048)   # the register-resident bucket sizes of qd_scale_digitize_histogram_f32
+
+
+def _fused_rescale_counts(q_tensor, scal, nsym, edges_dev):
+    """The counters of np.digitize(scal.scale_down(q_tensor)[:n], edges) from ONE pass over q_tensor
+    (qd_scale_digitize_histogram_f32), or None when the re-scale is not the plain bucketed linear one -- the caller then
+    re-scales and digitizes in two steps, as before.  Plain = this package's ScalingFunction, 'linear', no mean subtraction,
+    no max_element, a bucket size the kernel keeps in registers, a contiguous fp32 device tensor."""
+    from .. import _lib
+    from .quant_functions import ScalingFunction
+    if type(scal) is not ScalingFunction or scal.type_scaling != 'linear' or scal.subtract_mean or scal.max_element is not False:
+        return None
+    if scal.bucket_size not in FUSED_DIGITIZE_BUCKETS or nsym > DEVICE_HISTOGRAM_MAX_SYMBOLS or edges_dev is None:
+        return None
+    if not isinstance(q_tensor, torch.Tensor) or not q_tensor.is_cuda or q_tensor.dtype != torch.float32 or not q_tensor.is_contiguous():
+        return None
+    if q_tensor.data_ptr() % 16:
+        return None
+    lib = _lib.load()
+    with torch.cuda.device(q_tensor.device):
+        hist = torch.empty(nsym + 1, dtype=torch.int64, device=q_tensor.device)
+        ws = _lib.workspace(q_tensor.device)
+        rc = lib.qd_scale_digitize_histogram_f32(q_tensor.data_ptr(), q_tensor.numel(), int(scal.bucket_size), edges_dev.data_ptr(), nsym,
+                                                 hist.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(q_tensor.device))
+    if rc == _lib.QD_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc)
+    return hist
+
+
 def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_functions, type_quantization='uniform',
                                          s=None):
     """Mean Huffman code length (bits/weight) of the quantization indices of a model.
@@ -241,10 +272,12 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
     Same steps as the reference for every tensor -- call the quantization function, re-scale the quantized tensor with the
     scaling function it returned, digitize against the s level positions (uniform) or take the returned indices
     (non-uniform), count the symbols -- but the counting runs on the device: the reference copies every quantized tensor
-    to the host for np.digitize + np.unique (:215-223); here the digitize + histogram is one kernel over the re-scaled
-    tensor (qd_digitize_histogram_f32, same float64 comparison against the same edges) or over the int64 indices
-    (qd_histogram_i64), and only the s + 1 (k + 1) counters cross PCIe -- once per device, after the last tensor.  Tensors that cannot take that path (more than 256
-    symbols, or a quantization function that returns host tensors) are counted on the host exactly as before."""
+    to the host for np.digitize + np.unique (:215-223); here the re-scale, the digitize (same float64 comparison against
+    the same edges) and the histogram are ONE kernel over the quantized tensor (qd_scale_digitize_histogram_f32: 4 B read
+    per element) when the scaling function is the plain bucketed linear one, two kernels otherwise (scale_down, then
+    qd_digitize_histogram_f32), or one over the int64 indices (qd_histogram_i64) -- and only the s + 1 (k + 1) counters
+    cross PCIe, once per device, after the last tensor.  Tensors that cannot take that path (more than 256 symbols, or a
+    quantization function that returns host tensors) are counted on the host exactly as before."""
     type_quantization = type_quantization.lower()
     if type_quantization not in ('uniform', 'nonuniform'):
         raise ValueError('type_quantization not recognized')
@@ -258,11 +291,24 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
     tol = 1e-5
     edges = _digitize_edges(s, tol) if type_quantization == 'uniform' else None
     edges_dev, device_totals = {}, {}           # per device: the edges, the running int64 counters (uniform)
-    index_hists = {}                            # per device: [(counters of one tensor, its quantization function, the tensor)] (non-uniform)
+    index_hists = {}                            # per device: [(counters of one tensor, its int64 indices or None)] (non-uniform)
 
     def host_count(bins):
         for value, count in zip(*np.unique(bins, return_counts=True)):
             counts[value] += count
+
+    def flush_index_hists(pending):
+        if not pending:
+            return
+        table = torch.stack([h for h, _b in pending]).cpu().numpy()            # [tensors, MAX_SYMBOLS + 1]
+        fine = table[:, -1] == 0                             # last counter: indices outside the table
+        h = table[fine, :-1].sum(axis=0)
+        for value in np.nonzero(h)[0]:
+            counts[int(value)] += int(h[value])
+        for (_h, bins), ok in zip(pending, fine):            # the tensors with such indices: counted on the host, as the reference does
+            if not ok:
+                host_count(bins.cpu().numpy())
+        del pending[:]
 
     for pos, param in enumerate(model_param_iter):
         param = param.clone()
@@ -272,11 +318,13 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
         fn = quantization_functions[0] if shared else quantization_functions[pos]
         if type_quantization == 'uniform':
             q_tensor, scal = fn(param)
-            scaled = scal.scale_down(q_tensor).view(-1)[0:scal.original_tensor_length]
-            dev = scaled.device if isinstance(scaled, torch.Tensor) else None
+            dev = q_tensor.device if isinstance(q_tensor, torch.Tensor) else None
             if dev is not None and dev.type == 'cuda' and dev not in edges_dev:
                 edges_dev[dev] = torch.from_numpy(edges).to(dev)
-            hist = _device_counts('digitize', scaled, s, edges_dev.get(dev))
+            hist = _fused_rescale_counts(q_tensor, scal, s, edges_dev.get(dev))
+            if hist is None:
+                scaled = scal.scale_down(q_tensor).view(-1)[0:scal.original_tensor_length]
+                hist = _device_counts('digitize', scaled, s, edges_dev.get(dev))
             if hist is not None:                             # hist[c] = #{digitize == c}; the reference's bin is c - 1
                 device_totals[dev] = hist if dev not in device_totals else device_totals[dev] + hist
             else:
@@ -287,21 +335,21 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
             hist = _device_counts('index', bins, DEVICE_HISTOGRAM_MAX_SYMBOLS)
             if hist is None:
                 host_count(bins.cpu().numpy())
-            else:                                            # stays on the device: ONE copy per device at the end, not one per tensor
-                index_hists.setdefault(bins.device, []).append((hist, fn, param))
+            else:
+                # the counters stay on the device and are fetched for many tensors at once, not one copy per tensor.  The
+                # indices are kept until then -- if the table was too small for them (k > 256 points: last counter non-zero)
+                # they are counted on the host, as computed: no second call of a possibly stochastic `fn`, no clone of the
+                # parameter kept alive -- and a device never holds more than INDEX_RETAIN_BYTES of them
+                pending = index_hists.setdefault(bins.device, [])
+                pending.append((hist, bins))
+                if sum(b.numel() * 8 for _h, b in pending) > INDEX_RETAIN_BYTES:
+                    flush_index_hists(pending)
     for hist in device_totals.values():
         h = hist.cpu().numpy()
         for c in np.nonzero(h)[0]:
             counts[int(c) - 1] += int(h[c])
     for pending in index_hists.values():
-        table = torch.stack([h for h, _fn, _p in pending]).cpu().numpy()       # [tensors, MAX_SYMBOLS + 1]
-        fine = table[:, -1] == 0                             # last counter: indices outside the table
-        h = table[fine, :-1].sum(axis=0)
-        for value in np.nonzero(h)[0]:
-            counts[int(value)] += int(h[value])
-        for (_h, fn, param), ok in zip(pending, fine):       # the tensors with such indices: counted on the host, as the reference does
-            if not ok:
-                host_count(fn(param)[1].view(-1).cpu().numpy())
+        flush_index_hists(pending)
     assert total == sum(counts.values())
     freq = {sym: c / total for sym, c in counts.items()}
     return sum(freq[sym] * len(code) for sym, code in huffman_encode(freq))

@@ -41,7 +41,7 @@ def test_exports_match_header(lib):
 def test_host_only_entry_points(lib):
     # one number in three places: the header's QD_ABI_VERSION (what the library and _qd_glue.so compile in) and the Python binding's
     header = open(os.path.join(ROOT, 'include', 'qd_hip.h')).read()
-    assert int(re.search(r'#define QD_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == lib.qd_abi_version() == 2
+    assert int(re.search(r'#define QD_ABI_VERSION (\d+)', header).group(1)) == _lib.ABI_VERSION == lib.qd_abi_version() == 3
     assert lib.qd_target_arch() == b'gfx950'
     assert lib.qd_workspace_bytes() >= 64 * 1024
     assert lib.qd_error_string(0) == b'success'

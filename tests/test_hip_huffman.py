@@ -64,6 +64,57 @@ def test_digitize_histogram_equals_numpy():
     assert digitize_hist(torch.empty(0, device=DEV), edges).sum() == 0
 
 
+def test_one_pass_rescale_digitize_histogram_equals_the_two_kernel_form_and_numpy():
+    """qd_scale_digitize_histogram_f32 (re-scale + digitize + count in one pass over the quantized tensor) against (a) the
+    two-kernel form it replaces -- ScalingFunction.scale_down on the device, then qd_digitize_histogram_f32 -- and (b) numpy:
+    np.digitize of the oracle's scale_down, the reference's own steps (help_functions.py:215-218).  Bit-exact counters for
+    every register-resident bucket size, ragged lengths, quantized tensors and adversarial ones (raw values, buckets a few
+    ulps wide, constant buckets, NaN / inf buckets, denormal ranges)."""
+    from oracle import oracle_np as onp
+    rng = np.random.RandomState(11)
+    for bucket in qhf.FUSED_DIGITIZE_BUCKETS:
+        for s in (2, 4, 16, 256):
+            edges = qhf._digitize_edges(s, 1e-5)
+            edges_dev = torch.from_numpy(edges).to(DEV)
+            for n in (1, bucket - 1, bucket, bucket + 1, 7 * bucket + 5, 64 * bucket, (1 << 20) + 3 * bucket + 17):
+                x = rng.randn(n).astype(np.float32) * np.float32(rng.choice([1e-3, 0.05, 1.0, 300.0]))
+                kinds = [('quantized', host(quantization.uniformQuantization(dev(x), s, bucket_size=bucket)[0]))]
+                if s == 16:
+                    raw = x.copy()
+                    nb = n // bucket
+                    if nb >= 6:
+                        raw[0:bucket] = np.float32(1.0) + np.spacing(np.float32(1.0)) * rng.randint(0, 4, size=bucket).astype(np.float32)
+                        raw[bucket:2 * bucket] = 0.25                                    # constant: alpha -> 1
+                        raw[2 * bucket + 3] = np.nan                                     # the whole bucket becomes NaN
+                        raw[3 * bucket + 1] = np.inf
+                        raw[4 * bucket + 2] = -np.inf
+                        raw[5 * bucket:6 * bucket] = (rng.rand(bucket) * 1e-41).astype(np.float32)   # denormal range: IEEE division path
+                    kinds.append(('raw', raw))
+                for kind, q in kinds:
+                    qd = dev(q)
+                    sf = quantization.ScalingFunction('linear', False, False, bucket_size=bucket)
+                    got = qhf._fused_rescale_counts(qd, sf, s, edges_dev)
+                    assert got is not None, (bucket, s, n, kind)
+                    got = host(got)
+                    two = qhf._device_counts('digitize', sf.scale_down(qd).view(-1)[0:n], s, edges_dev)
+                    assert np.array_equal(got, host(two)), (bucket, s, n, kind, got, host(two))
+                    with np.errstate(all='ignore'):
+                        u = onp.scale_down(q, bucket)['u'].reshape(-1)[:n]
+                    assert np.array_equal(got, want_digitize(u, edges)), (bucket, s, n, kind)
+                    assert got.sum() == n
+    # what the one-pass form does not take: the caller falls back to the two-kernel form
+    q = dev(rng.randn(4096).astype(np.float32))
+    e16 = torch.from_numpy(qhf._digitize_edges(16, 1e-5)).to(DEV)
+    assert qhf._fused_rescale_counts(q, quantization.ScalingFunction('linear', False, False, bucket_size=100), 16, e16) is None
+    assert qhf._fused_rescale_counts(q, quantization.ScalingFunction('linear', False, False, bucket_size=None), 16, e16) is None
+    assert qhf._fused_rescale_counts(q, quantization.ScalingFunction('linear', False, True, bucket_size=256), 16, e16) is None
+    assert qhf._fused_rescale_counts(q, quantization.ScalingFunction('linear', 0.5, False, bucket_size=256), 16, e16) is None
+    assert qhf._fused_rescale_counts(q[1:], quantization.ScalingFunction('linear', False, False, bucket_size=256), 16, e16) is None   # 4-byte offset view
+    assert qhf._fused_rescale_counts(q.cpu(), quantization.ScalingFunction('linear', False, False, bucket_size=256), 16, e16) is None
+    empty = qhf._fused_rescale_counts(q[:0], quantization.ScalingFunction('linear', False, False, bucket_size=256), 16, e16)
+    assert empty is not None and int(empty.sum()) == 0
+
+
 def test_index_histogram_equals_numpy():
     rng = np.random.RandomState(1)
     for k_used in (1, 4, 16, 255, 256):
@@ -114,16 +165,26 @@ def test_boundary_function_equals_the_reference_on_the_student_shapes(monkeypatc
         if self.is_cuda:
             copied.append(self.numel())
         return real_cpu(self, *a, **kw)
-    for s, bucket in ((16, 256), (4, 256), (256, 256), (16, None), (4, None), (16, 100)):
+    one_pass = []
+    real_fused = qhf._fused_rescale_counts
+
+    def spy_fused(*a, **kw):
+        h = real_fused(*a, **kw)
+        one_pass.append(h is not None)
+        return h
+    for s, bucket in ((16, 256), (4, 256), (256, 256), (16, None), (4, None), (16, 100), (16, 64), (4, 2048)):
         want = refqhf.get_huffman_encoding_mean_bit_length(iter(params), lambda t: refq.uniformQuantization(t, s, bucket_size=bucket),
                                                            'uniform', s=s)
         monkeypatch.setattr(torch.Tensor, 'cpu', spy_cpu)
+        monkeypatch.setattr(qhf, '_fused_rescale_counts', spy_fused)
         got = qhf.get_huffman_encoding_mean_bit_length(iter(params_d), lambda t: quantization.uniformQuantization(t, s, bucket_size=bucket),
                                                        'uniform', s=s)
         monkeypatch.undo()
         assert abs(got - want) < 1e-12, (s, bucket, got, want)
         assert copied and max(copied) <= s + 1, (s, bucket, max(copied))
-        del copied[:]
+        # bucketed with a register-resident size: re-scale + digitize + count is ONE kernel per tensor; otherwise the two-kernel form
+        assert len(one_pass) == len(params) and all(one_pass) == (bucket in qhf.FUSED_DIGITIZE_BUCKETS) and any(one_pass) == all(one_pass), (s, bucket)
+        del copied[:], one_pass[:]
         # the level histogram of the codec gives the same lengths on such (non-degenerate) tensors
         if bucket in (256, None):
             assert abs(codec.huffman_mean_bit_length_uniform(params_d, s, bucket) - want) < 1e-12
@@ -306,7 +367,7 @@ def test_api_on_a_device_that_is_not_current():
 
 def test_boundary_function_property_vs_the_reference():
     """Random models (1-4 tensors of random sizes and value kinds -- ties, constant buckets, heavy tails, denormals, mixed
-    scales), s in {2, 4, 16, 256}, bucket in {None, 256, 100, 33, 7}: get_huffman_encoding_mean_bit_length of this package
+    scales), s in {2, 4, 16, 256}, bucket in {None, 256, 64, 1024, 100, 33, 7}: get_huffman_encoding_mean_bit_length of this package
     on the device equals the staged reference's on the host to 1e-12, whatever the values are."""
     import importlib
     import os
@@ -322,7 +383,7 @@ def test_boundary_function_property_vs_the_reference():
 
     @settings(max_examples=25 * soak, deadline=None, suppress_health_check=list(HealthCheck), derandomize=(soak == 1), database=None)
     @given(sizes=st.lists(st.integers(1, 30000), min_size=1, max_size=4), s=st.sampled_from([2, 4, 16, 256]),
-           bucket=st.sampled_from([None, 256, 256, 100, 33, 7]), seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 8))
+           bucket=st.sampled_from([None, 256, 256, 64, 1024, 100, 33, 7]), seed=st.integers(0, 2 ** 31 - 1), kind=st.integers(0, 8))
     def check(sizes, s, bucket, seed, kind):
         params = [torch.from_numpy(make(n, seed + i, kind if i % 2 == 0 else 0)) for i, n in enumerate(sizes)]
         with np.errstate(all='ignore'):
