@@ -208,7 +208,7 @@ class DistillTrainer(object):
         leaves this an eager trainer."""
         if self._capture_failed:
             # (measured: capturing again on a trainer whose earlier capture_shapes() died half-way ends in a segmentation fault
-            # inside the runtime -- profiles/r05_capture_probe.txt; a fresh trainer in the same process captures fine)
+            # inside the runtime -- docs/history/profiles/r05_capture_probe.txt; a fresh trainer in the same process captures fine)
             raise RuntimeError('an earlier capture on this trainer failed: discard it and capture on a fresh one')
         assert self.mode == 'multi', 'graph capture needs the persistent-shadow (multi) mode'
         assert self.style == 'none' and self.every == 1 and self._since >= 1, \

@@ -1,6 +1,6 @@
 """Achieved algorithmic bandwidth of every kernel on the path, measured the same way everywhere.
 
-(The `kernel` column names what rocprofv3 shows for the call -- tools/dispatch_map.py, profiles/r04_dispatch_map.txt; template
+(The `kernel` column names what rocprofv3 shows for the call -- tools/dispatch_map.py, docs/history/profiles/r04_dispatch_map.txt; template
 arguments: mode 0 = quantize-dequantize, 1 = scale_down, 2 = nearest point.)
 
 One table of rows (the headline's secondary rows and the per-kernel byte bases of
@@ -158,7 +158,7 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
         pts = torch.sort(torch.rand(k, device=dev, generator=gen))[0]
         add('K4 nonUniform k=%d b256 (int64 idx)' % k, 'k_bucket_vec<2,16,4,1>',
             lambda i, pts=pts: keep(i, quantization.nonUniformQuantization(xs[i % R], pts, bucket_size=256)[:2]), 16, N,
-            note='q and the int64 indices of the last 4 calls stay alive; 177-201 us box to box with one binary (profiles/r04_ab_idx_stores.txt)')
+            note='q and the int64 indices of the last 4 calls stay alive; 177-201 us box to box with one binary (docs/history/profiles/r04_ab_idx_stores.txt)')
         if k == 4:
             add('K4 nonUniform k=4 b256 (uint8 idx: index_dtype opt-in)', 'k_bucket_vec<2,16,4,1>',
                 lambda i, pts=pts: keep(i, quantization.nonUniformQuantization(xs[i % R], pts, bucket_size=256, index_dtype=torch.uint8)[:2]), 9, N,

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t* packed, float* y,
 // 8 float4 stores from there: HBM traffic 1.009 x the algorithmic bytes against 1.064 x for this kernel by the PMC counters,
 // but 56-60 us against 47.9 us at 64 Mi elements, with or without a resident grid, the next chunk's load in flight, or a level
 // table in LDS.  Here the whole grid sweeps the output front to back, 1 KiB per wave and store; there every wave streams
-// into its own 8 KiB region, thousands of concurrent write streams.  profiles/r04_ab_codec.txt.)
+// into its own 8 KiB region, thousands of concurrent write streams.  docs/history/profiles/r04_ab_codec.txt.)
 // uint8 level indices -> packed bits (any bucket geometry: the levels come from qd_uniform_f32's level_idx output).
 // Every thread produces one 32-bit word = 32 / BITS levels; the last, partial word byte by byte.
 template <int BITS>

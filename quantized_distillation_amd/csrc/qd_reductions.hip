@@ -684,12 +684,12 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
             xv[j] = __builtin_nontemporal_load((const f4*)(x + e0) + j * LPB);
             gv[j] = __builtin_nontemporal_load((const f4*)(g + e0) + j * LPB);
         }
-        float mn = INFINITY, mx = -INFINITY;
+        // NaN-propagating, as torch's min / max and as the forward kernel: a bucket that holds a NaN (or an infinity: alpha =
+        // inf) quantizes to NaN as a whole, its sum S is NaN, and the reference adds and subtracts S at the FIRST NaN -- the
+        // position torch's min and max both report (quant_functions.py:350,383-400)
+        float mn = pmin4(xv[0]), mx = pmax4(xv[0]);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            mn = fminf(mn, fminf(fminf(xv[j].x, xv[j].y), fminf(xv[j].z, xv[j].w)));
-            mx = fmaxf(mx, fmaxf(fmaxf(xv[j].x, xv[j].y), fmaxf(xv[j].z, xv[j].w)));
-        }
+        for (int j = 1; j < V; ++j) { mn = pmin(mn, pmin4(xv[j])); mx = pmax(mx, pmax4(xv[j])); }
         mn = group_min<LPB>(mn); mx = group_max<LPB>(mx);
         float a, b;
         alpha_beta(mn, mx, a, b);
@@ -712,17 +712,15 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
         const bool fa = !__any(!fastdiv_ok(a));              // wave-uniform
         if (fa) { if (use_tab) quantize(std::true_type{}, std::true_type{}); else quantize(std::true_type{}, std::false_type{}); }
         else { if (use_tab) quantize(std::false_type{}, std::true_type{}); else quantize(std::false_type{}, std::false_type{}); }
-        float qmn = INFINITY, qmx = -INFINITY;
+        float qmn = pmin4(qv[0]), qmx = pmax4(qv[0]);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            qmn = fminf(qmn, fminf(fminf(qv[j].x, qv[j].y), fminf(qv[j].z, qv[j].w)));
-            qmx = fmaxf(qmx, fmaxf(fmaxf(qv[j].x, qv[j].y), fmaxf(qv[j].z, qv[j].w)));
-        }
+        for (int j = 1; j < V; ++j) { qmn = pmin(qmn, pmin4(qv[j])); qmx = pmax(qmx, pmax4(qv[j])); }
         qmn = group_min<LPB>(qmn); qmx = group_max<LPB>(qmx);
         float aq, bq;
         alpha_beta(qmn, qmx, aq, bq);                       // scale_down of the QUANTIZED bucket, :350
         int jmax = 0x7fffffff, jmin = 0x7fffffff;           // index inside the bucket
         const bool ref_tie = tie_mode == QD_STE_TIE_REFERENCE;
+        const bool bad = ref_tie ? (qmn != qmn) : (mn != mn);   // the searched tensor's min / max are NaN: both sit at its first NaN
         bool tiny = false;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -730,8 +728,9 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
 #define QD_STE_ELEM(c, off)                                                          \
             {                                                                        \
                 tiny |= ste_tiny_numerator(xv[j].c, bq);                             \
-                const bool top = ref_tie ? (qv[j].c == qmx) : (xv[j].c == mx);       \
-                const bool bot = ref_tie ? (qv[j].c == qmn) : (xv[j].c == mn);       \
+                const float sv = ref_tie ? qv[j].c : xv[j].c;                        \
+                const bool top = bad ? (sv != sv) : (sv == (ref_tie ? qmx : mx));    \
+                const bool bot = bad ? (sv != sv) : (sv == (ref_tie ? qmn : mn));    \
                 jmax = (top && base + off < jmax) ? base + off : jmax;               \
                 jmin = (bot && base + off < jmin) ? base + off : jmin;               \
             }
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(256) void k_ste_backward_vec(const float* x, const 
         };
         if (!__any(!fastdiv_ok(aq) || tiny)) bucket_sum(std::true_type{}); else bucket_sum(std::false_type{});
         sum = group_sum<LPB>(sum); jmax = group_imin<LPB>(jmax); jmin = group_imin<LPB>(jmin);
-        const bool touch = jmax != jmin;                    // constant bucket: +S and -S cancel
+        const bool touch = jmax != jmin || bad;             // constant bucket: +S and -S cancel; a NaN bucket: (g + S) - S = NaN there
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int base = (j * LPB + l) * 4;
@@ -780,21 +779,25 @@ __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const floa
         const int64_t hi = lo + row < n ? lo + row : n;
         // pass 1: alpha/beta of x
         float mn = INFINITY, mx = -INFINITY;
-        for (int64_t i = lo + lane; i < hi; i += 64) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        bool nan = false;
+        for (int64_t i = lo + lane; i < hi; i += 64) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); nan |= (v != v); }
         mn = wave_min(mn); mx = wave_max(mx);
+        if (group_any<64>(nan)) { mn = NAN; mx = NAN; }      // torch's min / max propagate a NaN (as the register-resident path does)
         float a, b;
         alpha_beta(mn, mx, a, b);
         // pass 2: min/max of the QUANTIZED bucket (the reference re-runs scale_down on q, :350)
         float qmn = INFINITY, qmx = -INFINITY;
-        bool tiny = false;
+        bool tiny = false, qnan = false;
         for (int64_t i = lo + lane; i < hi; i += 64) {
             float lev;
             const float q = qdq(x[i], a, b, sm1, 0.0f, lev);
-            qmn = fminf(qmn, q); qmx = fmaxf(qmx, q);
+            qmn = fminf(qmn, q); qmx = fmaxf(qmx, q); qnan |= (q != q);
         }
         qmn = wave_min(qmn); qmx = wave_max(qmx);
+        if (group_any<64>(qnan)) { qmn = NAN; qmx = NAN; }
         float aq, bq;
         alpha_beta(qmn, qmx, aq, bq);
+        const bool bad = tie_mode == QD_STE_TIE_REFERENCE ? (qmn != qmn) : (mn != mn);   // min / max of the searched tensor are NaN: both at its first NaN
         for (int64_t i = lo + lane; i < hi; i += 64) tiny |= ste_tiny_numerator(x[i], bq);
         // pass 3: S_b (the reference's own per-element operations, :400) and the first index at the top / bottom level
         // (or the true arg of x)
@@ -808,8 +811,9 @@ __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const floa
                 const float xv = x[i];
                 const float q = qdq(xv, a, b, sm1, 0.0f, lev);
                 s += ste_term<FAST>(g[i], q, xv, aq, bq, yq);
-                const bool top = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmx) : (xv == mx);
-                const bool bot = tie_mode == QD_STE_TIE_REFERENCE ? (q == qmn) : (xv == mn);
+                const float sv = tie_mode == QD_STE_TIE_REFERENCE ? q : xv;
+                const bool top = bad ? (sv != sv) : (sv == (tie_mode == QD_STE_TIE_REFERENCE ? qmx : mx));
+                const bool bot = bad ? (sv != sv) : (sv == (tie_mode == QD_STE_TIE_REFERENCE ? qmn : mn));
                 if (top && (long long)i < jmax) jmax = i;
                 if (bot && (long long)i < jmin) jmin = i;
             }
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(256) void k_ste_backward(const float* x, const floa
         // pass 4: out = g, +S at jmax, -S at jmin (they cancel when the bucket is constant)
         for (int64_t i = lo + lane; i < hi; i += 64) {
             float o = g[i];
-            if (jmax != jmin) {
+            if (jmax != jmin || bad) {                     // (a NaN bucket: (g + S) - S = NaN at the first NaN, as the reference)
                 if (i == jmax) o = o + s;
                 if (i == jmin) o = o - s;
             }

@@ -413,7 +413,7 @@ __device__ __forceinline__ void store_side4_row(const KParams& p, int64_t e, con
         const l2 va = {(int64_t)(ca & 0xFFFFu), (int64_t)(ca >> 16)}, vb = {(int64_t)(cb & 0xFFFFu), (int64_t)(cb >> 16)};
         l2* o = (l2*)((int64_t*)p.idx + (e - (int64_t)l16 * 4));          // the row's first element
         o[l16] = va;                  // plain stores: 175.8 us vs 180.0 us with the non-temporal hint (k = 4, round 3); round 4, index output
-        o[16 + l16] = vb;             // kept alive by the caller: 201.0 vs 199.4 us, no difference either way (profiles/r04_ab_idx_stores.txt)
+        o[16 + l16] = vb;             // kept alive by the caller: 201.0 vs 199.4 us, no difference either way (docs/history/profiles/r04_ab_idx_stores.txt)
     } else {
         store_side4<MODE>(p, e, s);
     }
@@ -422,7 +422,7 @@ __device__ __forceinline__ void store_side4_row(const KParams& p, int64_t e, con
 // (Round 4 measured the whole-wave form of this exchange -- each store instruction one contiguous KiB instead of four 256-byte
 // pieces at a 512-byte stride -- on the stream kernel: 189.7 us both ways.  The layout of the index stores is not what holds
 // the int64 calls at 67-71 % of the HBM peak; torch's own fp32 -> int64 conversion, the same 1 : 2 read : write mix, is the
-// yardstick: profiles/r04_ab_idx_stores.txt.)
+// yardstick: docs/history/profiles/r04_ab_idx_stores.txt.)
 // ---- LANES lanes (16 = one DPP row, 64 = a wave) process one arbitrary bucket [lo, hi): scalar
 // accesses, two passes (the second pass re-reads from L1/L2).  Used for the ragged last bucket,
 // short buckets, odd bucket sizes and the multi-tensor kernel's unaligned cases.

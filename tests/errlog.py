@@ -4,7 +4,7 @@ result").  Everything else on the path is bit-exact and never comes through here
 
 Every check also RECORDS the error it achieved (error / sum|terms|) as one JSON line in gpurun_out/reduction_error.jsonl,
 so that the margin is known, not assumed; tools/summarize_reduction_error.py turns the log of a GPU run into
-profiles/r04_reduction_error.txt.
+docs/history/profiles/r04_reduction_error.txt.
 """
 import json
 import os

@@ -105,7 +105,7 @@ def test_point_gradient_vs_the_staged_reference_on_wrn_shapes():
     """K6 against the REFERENCE's own fp32 `gradPointTensor` (quant_functions.py:493-503: k masked_select + sum passes on
     the host) at WideResNet-16-22 tensor shapes, incl. the largest one (1408 x 1408 x 3 x 3 = 17.8 M elements): the distance
     is the sum of both sides' fp32 summation errors and must stay inside north_star's 1e-6 of sum |g alpha|; the distance
-    of each side from the float64 oracle is recorded next to it (profiles/r04_reduction_error.txt)."""
+    of each side from the float64 oracle is recorded next to it (docs/history/profiles/r04_reduction_error.txt)."""
     from oracle import ref_stage
     refq = ref_stage.load()
     if refq is None:

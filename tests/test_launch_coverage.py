@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
-RECORD = os.path.join(ROOT, 'profiles', 'r05_launch_coverage.json')
+RECORD = os.path.join(ROOT, 'profiles', 'r06_launch_coverage.json')
 
 
 def test_every_shipped_kernel_is_launched_by_a_test():

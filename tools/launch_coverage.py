@@ -11,7 +11,7 @@ it a test).
     python tools/launch_coverage.py --run [pytest args ...]     on the GPU box; writes gpurun_out/launch_coverage.{json,txt}
     python tools/launch_coverage.py --check FILE.json           anywhere: the committed record against the library as built NOW
 
-tests/test_launch_coverage.py asserts --check on the committed profiles/r05_launch_coverage.json, so a dispatch change that
+tests/test_launch_coverage.py asserts --check on the committed profiles/r06_launch_coverage.json, so a dispatch change that
 adds an instantiation fails the CPU suite until the coverage run has been repeated.
 
 Kernels are matched by their demangled name without the argument list.  The same template can be instantiated in several

@@ -3,7 +3,7 @@
 floating-point reduction of the path ACHIEVED, relative to the sum of the magnitudes of its terms, next to the tolerance
 it is held to (north_star: 1e-6).
 
-    python tools/summarize_reduction_error.py [log] > profiles/r04_reduction_error.txt
+    python tools/summarize_reduction_error.py [log] > docs/history/profiles/r04_reduction_error.txt
 """
 import collections
 import json
