@@ -507,8 +507,9 @@ def worker_main(args):
     snapshot()
     if reporter.fd is None and rank == 0:                          # `bench.py --worker` run by hand: no guardian to print the line
         from harness import report
-        if report.write_detail(args.detail, line):
-            line['detail'] = os.path.basename(args.detail)
+        line['detail'] = os.path.basename(args.detail)
+        if not report.write_detail(args.detail, line):
+            del line['detail']
         print(report.fit(report.compact(line)), flush=True)
     runner.barrier()                                               # (gloo: works whatever the legs left behind)
     if dist.is_initialized():

@@ -158,8 +158,10 @@ def supervise(worker_cmd, all_legs, rank=0, world=1, wall_limit_s=1500.0, max_re
             if line.get('value') is None and 'error' not in line:
                 line['error'] = 'the worker ended before the headline was measured (%s); see stderr' % (code_hint,)
             line['bench_process'] = info
-            if detail_path and report.write_detail(detail_path, line, log):
+            if detail_path:
                 line['detail'] = os.path.basename(detail_path)
+                if not report.write_detail(detail_path, line, log):
+                    del line['detail']
             log('bench record (full): ' + json.dumps(line))
             out.write(report.fit(compact(line)) + '\n')
             out.flush()

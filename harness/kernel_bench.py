@@ -206,7 +206,7 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
     sf = quantization.ScalingFunction('linear', False, False, bucket_size=256)
     add('HUF re-scale + digitize + count of q, s=16 b256 (one pass)', 'k_scale_digitize_hist_vec<16,4>+k_hist_fold',
         lambda i: qhf._fused_rescale_counts(qs[i % R], sf, 16, e16), 4, N, note='4 B read, nothing written')
-    add('HUF the two-kernel form it replaces (scale_down, then digitize + count)', 'k_bucket_vec<1,16,4,1>+k_hist_sym<0>+k_hist_fold',
+    add('HUF2 the two-kernel form it replaces (scale_down, then digitize + count)', 'k_bucket_vec<1,16,4,1>+k_hist_sym<0>+k_hist_fold',
         lambda i: qhf._device_counts('digitize', sf.scale_down(qs[i % R]).view(-1), 16, e16), 12, N, note='4 r + 4 w, then 4 r')
     del qs
     live[:] = [None] * R
