@@ -54,6 +54,22 @@ def test_digitize_histogram_equals_numpy():
                     continue
                 got = digitize_hist(dev(v)[off:], edges)
                 assert np.array_equal(got, want_digitize(v[off:], edges)), (s, n, off)
+    # the float32 neighbourhood of every edge: the kernel compares in float32 against thr[j] = the smallest float32 whose
+    # promotion is >= edges[j]; one ulp either side of every edge must land where numpy's float64 comparison puts it
+    for s in (2, 16, 255, 256):
+        edges = qhf._digitize_edges(s, 1e-5)
+        f = edges.astype(np.float32)
+        v = np.concatenate([f, np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf)),
+                            np.nextafter(np.nextafter(f, np.float32(np.inf)), np.float32(np.inf))]).astype(np.float32)
+        assert np.array_equal(digitize_hist(dev(v), edges), want_digitize(v, edges)), s
+    # edges float32 cannot hold: beyond its range, inside its denormals, zeros of either sign, exactly representable ones
+    edges = np.array([-1e300, -3.5e38, -1.0, -1e-320, -0.0, 1e-320, 1e-46, 1.401298464324817e-45, 1e-40, 0.1, 0.5, 1.0, 3.4028234663852886e38,
+                      3.5e38, 1e300], dtype=np.float64)
+    f = edges.astype(np.float32)
+    v = np.concatenate([f, np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf)),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4028235e38, -3.4028235e38], dtype=np.float32)]).astype(np.float32)
+    with np.errstate(all='ignore'):
+        assert np.array_equal(digitize_hist(dev(v), edges), want_digitize(v, edges))
     # edges that are not evenly spaced (the walk from the linear guess), duplicates of the first / last region
     edges = np.sort(np.concatenate([rng.rand(40) ** 3, [0.0, 0.5, 0.5000001, 1.0]]))
     v = rng.rand(1 << 18).astype(np.float32) * 1.2 - 0.1
