@@ -290,7 +290,7 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
     total = 0
     tol = 1e-5
     edges = _digitize_edges(s, tol) if type_quantization == 'uniform' else None
-    edges_dev, device_totals = {}, {}           # per device: the edges, the running int64 counters (uniform)
+    edges_dev, device_totals = {}, {}           # per device: the edges, the int64 counters of every tensor (uniform)
     index_hists = {}                            # per device: [(counters of one tensor, its int64 indices or None)] (non-uniform)
 
     def host_count(bins):
@@ -326,7 +326,7 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
                 scaled = scal.scale_down(q_tensor).view(-1)[0:scal.original_tensor_length]
                 hist = _device_counts('digitize', scaled, s, edges_dev.get(dev))
             if hist is not None:                             # hist[c] = #{digitize == c}; the reference's bin is c - 1
-                device_totals[dev] = hist if dev not in device_totals else device_totals[dev] + hist
+                device_totals.setdefault(dev, []).append(hist)   # summed once per device at the end: no add launch per tensor
             else:
                 host_count(np.digitize(scaled.cpu().numpy(), edges).flatten() - 1)
         else:
@@ -344,8 +344,8 @@ def get_huffman_encoding_mean_bit_length(model_param_iter, quantization_function
                 pending.append((hist, bins))
                 if sum(b.numel() * 8 for _h, b in pending) > INDEX_RETAIN_BYTES:
                     flush_index_hists(pending)
-    for hist in device_totals.values():
-        h = hist.cpu().numpy()
+    for hists in device_totals.values():
+        h = (hists[0] if len(hists) == 1 else torch.stack(hists).sum(dim=0)).cpu().numpy()
         for c in np.nonzero(h)[0]:
             counts[int(c) - 1] += int(h[c])
     for pending in index_hists.values():
