@@ -428,7 +428,7 @@ PyObject* glue_point_grad(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
 PyObject* glue_abi_version(PyObject*, PyObject*) { return PyLong_FromLong(QD_ABI_VERSION); }
 
 // host_cost_probe(x, levels, bucket, iters) -> (us per bare C-ABI launch, us per output allocation pair, us per launch with
-// allocation).  Measurement aid for tools/profile_api_overhead.py: where the per-call host time of uniform() goes.
+// allocation).  Measurement aid for docs/history/tools/profile_api_overhead.py: where the per-call host time of uniform() goes.
 PyObject* glue_host_cost_probe(PyObject*, PyObject* const* args, Py_ssize_t nargs) {
     HANDLE_TH_ERRORS
     if (nargs != 4) {
