@@ -183,7 +183,9 @@ def run(dev, log2n=26, sweeps=False, marker=None, verbose=False, only=None, hist
     st_ptr = _lib.stream_ptr
     add('K8 truncated STE mask, 32% of |w| > 1', 'k_truncated_ste',
         lambda i: lib.qd_truncated_ste_f32(xs[i % R].data_ptr(), gs[i % R].data_ptr(), N, 1.0, st_ptr()), 12, N,
-        note='adversarial: w read + g read-modify-write')
+        note="adversarial density; SURVEY 8d's basis (w read, g read + written). Zero stores that never read g take the same time "
+             '(profiles/r06_ab_k8.txt): a partly written line is read-modified-written at the memory side; PMC: ~10 B/elem moved; the '
+             'minimal 4 + 4 x 0.32 = 5.3 B/elem would read 0.30')
     ws_ = [x * 0.2 for x in xs]
     add('K8 truncated STE mask, nothing masked', 'k_truncated_ste',
         lambda i: lib.qd_truncated_ste_f32(ws_[i % R].data_ptr(), gs[i % R].data_ptr(), N, 1.0, st_ptr()), 4, N, note='w read only')
