@@ -92,9 +92,13 @@ def compact(line):
             ro['kernel_rows'] = len(rows)
         out['roofline'] = ro
         if rows:
-            # one number per row, keyed by the row's tag (its first word: K1, K2, K6m, PK, ...); a tag that repeats keeps its worst
+            # one number per row, keyed by the row's tag (its first word: K1, K2, K6m, PK, ...); a tag that repeats keeps its worst.
+            # Rows below 16 Mi elements (the 1 M-parameter CIFAR student: one 8 us launch) are launch-bound, a fraction of the HBM
+            # peak says nothing about them: full record only, as for worst_kernel
             kf = {}
             for x in rows:
+                if x.get('n', 0) < 1 << 24:
+                    continue
                 tag = str(x.get('name', '?')).split(' ')[0][:6]
                 kf[tag] = min(kf.get(tag, 9.0), _num(x['frac'], 3))
             out['kernels_frac'] = kf
