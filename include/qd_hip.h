@@ -55,7 +55,8 @@ extern "C" {
 /* Library identification: ABI version (bumped on every change of an entry point's meaning or signature) and target arch.
  * History: 1 = rounds 1-3; 2 = qd_nearest_point_f32 accepts q == NULL (indices only), qd_uniform_f32 accepts q == NULL with
  * level_idx (levels only), qd_selftest_div_invariant, qd_digitize_histogram_f32 / qd_histogram_i64 / qd_level_histogram_f32
- * added, 4-byte data alignment; 3 = qd_scale_digitize_histogram_f32 added.
+ * added, 4-byte data alignment; 3 = qd_scale_digitize_histogram_f32 added, QdDiffQuantDesc.first_row (partial rows of
+ * qd_multi_point_grad_f32 per tensor size instead of 4 B + 1 for every tensor).
  * The Python binding and _qd_glue.so compare the version THEY were built for with the library's. */
 #define QD_ABI_VERSION 3
 int qd_abi_version(void);
@@ -216,11 +217,12 @@ typedef struct QdDiffQuantDesc {
     int64_t n;
     int64_t first_tile;   /* filled by qd_multi_dq_plan: prefix of 4-bucket tiles (forward) */
     int64_t first_block;  /* filled by qd_multi_dq_plan: prefix of FULL 1024-element gradient tiles (backward) */
+    int64_t first_row;    /* filled by qd_multi_dq_plan: prefix of the backward sweep's partial rows (ABI 3)  */
 } QdDiffQuantDesc;
-/* Host helper: fills first_tile / first_block, returns the total of forward tiles, writes `total_blocks` = the number of
- * partial rows of the backward sweep, ntensors * (4 B + 1), B = its main grid (min(512, ceil(full gradient tiles / 4))
- * blocks whose 4 B waves stride over the ONE sequence of all tensors' full tiles; one more wave per tensor takes the
- * n mod 1024 elements left).  Pass it to qd_multi_point_grad_f32 unchanged. */
+/* Host helper: fills first_tile / first_block / first_row, returns the total of forward tiles, writes `total_blocks` = the
+ * number of partial rows of the backward sweep: min(full 1024-element gradient tiles, 2048) + 1 per tensor (the 2048 waves of
+ * the main grid stride over the ONE sequence of all tensors' full tiles and write one row per tensor they visit; one more
+ * wave per tensor takes the n mod 1024 elements left).  Pass it to qd_multi_point_grad_f32 unchanged. */
 int64_t qd_multi_dq_plan(QdDiffQuantDesc* host_table, int ntensors, int64_t bucket, int64_t* total_blocks_out);
 int qd_multi_nearest_f32(const QdDiffQuantDesc* table, int ntensors, int64_t total_tiles, int64_t bucket,
                          const float* points, int k, void* stream);

@@ -46,7 +46,7 @@ class QdDiffQuantDesc(ctypes.Structure):
     """Mirror of `struct QdDiffQuantDesc` in include/qd_hip.h."""
     _fields_ = [('u', ctypes.c_void_p), ('q', ctypes.c_void_p), ('idx', ctypes.c_void_p), ('alpha', ctypes.c_void_p),
                 ('beta', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('n', ctypes.c_int64),
-                ('first_tile', ctypes.c_int64), ('first_block', ctypes.c_int64)]
+                ('first_tile', ctypes.c_int64), ('first_block', ctypes.c_int64), ('first_row', ctypes.c_int64)]
 
 
 # symbol -> (restype, argtypes); every symbol declared in include/qd_hip.h must be listed here

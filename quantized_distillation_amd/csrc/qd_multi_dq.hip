@@ -111,12 +111,15 @@ __global__ __launch_bounds__(256) void k_multi_nearest(const QdDiffQuantDesc* __
 //            streaming windows are worse than 60; the wave-strided sequence WITH the partial tiles in it: 74.2 us (on ONE 64 Mi
 //            tensor 54.7 us, the single-tensor kernel's time, against 65.2 us for round 4's) -- 47 of the 60 WRN tensors end
 //            in a partial tile, 43 are nothing else, and each cost one of the 40-tile waves a slow masked tile + two flushes
-// Partial sums: a wave keeps its bins while its tiles stay in one tensor and writes them out -- one row of k floats at
-// [ti][g] -- when they move on to the next one; the extra wave of tensor ti writes row [ti][W].  Which rows exist is a function
-// of the table alone (tensor ti with c full tiles from f0 on: waves (f0 + i) mod W, i < min(c, W); row W iff n mod 1024), so the
-// fold reads exactly the rows that were written and nothing needs zeroing.  Fixed tile -> wave assignment, fixed fold order:
-// deterministic.
+// Partial sums: a wave keeps its bins while its tiles stay in one tensor and writes them out -- one row of k floats -- when they
+// move on to the next one.  Tensor ti with c full tiles from f0 on is visited by the waves (f0 + i) mod W, i < min(c, W), each
+// once: wave g writes row first_row[ti] + ((g - f0) mod W) and the extra wave of the tensor row first_row[ti] + min(c, W), so a
+// tensor owns min(c, W) + 1 rows (round 6: it owned W + 1 whatever its size -- 105 MB of scratch for 200 small tensors at
+// k = 64) and the fold reads them front to back.  Which rows exist is a function of the table alone, so nothing needs zeroing.
+// Fixed tile -> wave assignment, fixed fold order: deterministic.
 constexpr int kGradTile = 1024;
+constexpr int kGradBlocks = 512;                       // the main grid: 2048 waves x 4 independent 1 KiB streams, the shape that
+constexpr int64_t kGradWaves = 4 * kGradBlocks;        // measured best for qd_point_grad_f32; blocks beyond the last tile return at once
 
 // T is not an argument of the entry point (the host holds no copy of the device table): the last tensor's prefix + its tiles
 __device__ __forceinline__ int64_t total_grad_tiles(const QdDiffQuantDesc* table, int ntensors) {
@@ -137,12 +140,13 @@ __device__ __forceinline__ int owner_of_tile(const QdDiffQuantDesc* table, int n
 
 // KR > 0: k <= KR bins in registers (compare-select-add); KR == 0: lane-private LDS columns [k][256]
 template <int KR>
-__global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc* __restrict__ table, int ntensors, int B,
-                                                          int64_t bucket, int row_shift, int k, float* part /* [ntensors][4 B + 1][k] */) {
+__global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc* __restrict__ table, int ntensors,
+                                                          int64_t bucket, int row_shift, int k, float* part /* [rows][k] */) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // KR == 0: [k][256]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t W = (int64_t)B * 4;
+    constexpr int B = kGradBlocks;
+    constexpr int64_t W = kGradWaves;
     float acc[KR > 0 ? KR : 1];
     float* col = lds + threadIdx.x;                                    // this lane's column; a wave owns columns 64 w ... 64 w + 63
     auto clear = [&]() {
@@ -161,8 +165,12 @@ __global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc*
             col[id * 256] += m;                                        // private column: plain LDS read-add-write
         }
     };
-    auto flush = [&](int ti, int64_t r) {                              // this wave's sums for tensor ti -> row [ti][r], bins cleared
-        float* row = part + ((int64_t)ti * (W + 1) + r) * k;
+    auto flush = [&](const QdDiffQuantDesc& dd, int64_t r) {           // this wave's sums for tensor dd -> its row for wave r (W: the extra wave), bins cleared
+        const int64_t full = dd.n / kGradTile;
+        int64_t c = r - dd.first_block % W;                            // (r - f0) mod W for a wave of the main grid
+        c = c < 0 ? c + W : c;
+        c = r == W ? (full < W ? full : W) : c;
+        float* row = part + (dd.first_row + c) * k;
         if (KR > 0) {
 #pragma unroll
             for (int j = 0; j < (KR > 0 ? KR : 1); ++j) {
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc*
         } else {
             scalar_span(d, e0, d.n);
         }
-        flush(ti, W);
+        flush(d, W);
         return;
     }
 
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc*
     int64_t next_first = ti + 1 < ntensors ? table[ti + 1].first_block : T;
     for (int64_t t = g; t < T; t += W) {
         if (t >= next_first) {                                          // this wave's tiles have moved on to a later tensor
-            flush(ti, g);
+            flush(d, g);
             do {
                 ++ti;
                 next_first = ti + 1 < ntensors ? table[ti + 1].first_block : T;
@@ -290,24 +298,22 @@ __global__ __launch_bounds__(256) void k_multi_point_grad(const QdDiffQuantDesc*
             scalar_span(d, e0, e0 + kGradTile);
         }
     }
-    flush(ti, g);
+    flush(d, g);
 }
 
-// backward stage 2: block (tensor, bin) folds the rows that tensor's waves wrote, in a fixed order.  Up to 2048 + 1 rows per
+// backward stage 2: block (tensor, bin) folds the rows that tensor's waves wrote, front to back.  Up to 2048 + 1 rows per
 // tensor: 256 threads, eight independent loads in flight each (one dependent load per row and thread was 32 round trips =
 // ~12 us on the WRN shape list, more than the sweep gained).
 __global__ __launch_bounds__(256) void k_multi_point_grad_final(const QdDiffQuantDesc* __restrict__ table, int ntensors,
-                                                                int64_t W, int k, const float* part,
+                                                                int k, const float* part,
                                                                 float* grad_points /* [ntensors][k] */) {
     __shared__ double s_w[4];
-    const int64_t T = total_grad_tiles(table, ntensors);
+    constexpr int64_t W = kGradWaves;
     const int ti = blockIdx.x / k, j = blockIdx.x % k;
-    const int64_t f0 = table[ti].first_block;
-    const int64_t f1 = ti + 1 < ntensors ? table[ti + 1].first_block : T;
-    const int64_t rows = f1 - f0 < W ? f1 - f0 : W;                     // waves (f0 + i) mod W, i < rows, had a tile of this tensor
-    const float* base = part + (int64_t)ti * (W + 1) * k + j;
-    const int64_t r0 = f0 % W;
-    auto row = [&](int64_t i) { int64_t r = r0 + i; r = r >= W ? r - W : r; return base[r * k]; };
+    const int64_t full = table[ti].n / kGradTile;
+    const int64_t rows = full < W ? full : W;                           // row i: wave (f0 + i) mod W, the i-th of the waves that had a tile of this tensor
+    const float* base = part + table[ti].first_row * k + j;
+    auto row = [&](int64_t i) { return base[i * k]; };
     double acc = 0.0;
     int64_t i = threadIdx.x;
     for (; i + 7 * 256 < rows; i += 8 * 256) {
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void k_multi_point_grad_final(const QdDiffQuan
         for (int u = 0; u < 8; ++u) acc += (double)v[u];
     }
     for (; i < rows; i += 256) acc += (double)row(i);
-    if (threadIdx.x == 0 && (table[ti].n % kGradTile) != 0) acc += (double)base[W * k];      // the extra wave's row
+    if (threadIdx.x == 0 && (table[ti].n % kGradTile) != 0) acc += (double)base[rows * k];   // the extra wave's row
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -329,29 +335,22 @@ __global__ __launch_bounds__(256) void k_multi_point_grad_final(const QdDiffQuan
 
 extern "C" {
 
-// blocks of the gradient grid for T tiles: 512 blocks -- 2048 waves x 4 independent 1 KiB streams, the shape that measured
-// best for qd_point_grad_f32 (qd_reductions.hip) -- and no more than one wave per tile
-static int64_t grad_blocks(int64_t T) {
-    int64_t B = (T + 3) / 4;
-    if (B > 512) B = 512;
-    if (B < 1) B = 1;
-    return B;
-}
-
 int64_t qd_multi_dq_plan(QdDiffQuantDesc* host_table, int ntensors, int64_t bucket, int64_t* total_blocks_out) {
     if (!host_table || ntensors <= 0 || bucket <= 0 || !total_blocks_out) return -1;
-    int64_t tiles = 0, gtiles = 0;
+    int64_t tiles = 0, gtiles = 0, rows = 0;
     for (int i = 0; i < ntensors; ++i) {
         const int64_t n = host_table[i].n;
         const int64_t row = n < bucket ? (n > 0 ? n : 1) : bucket;
         const int64_t nb = n > 0 ? (n + row - 1) / row : 0;
         host_table[i].first_tile = tiles;
         host_table[i].first_block = gtiles;              // prefix of FULL 1024-element gradient tiles (k_multi_point_grad)
+        host_table[i].first_row = rows;                  // prefix of partial rows: min(full tiles, 2048) + 1 per tensor
+        const int64_t full = n > 0 ? n / kGradTile : 0;
         tiles += (nb + 3) / 4;
-        gtiles += n > 0 ? n / kGradTile : 0;
+        gtiles += full;
+        rows += (full < kGradWaves ? full : kGradWaves) + 1;
     }
-    // partial rows of the gradient sweep: [ntensors][4 B + 1], see k_multi_point_grad
-    *total_blocks_out = (4 * grad_blocks(gtiles) + 1) * ntensors;
+    *total_blocks_out = rows;                            // partial rows of the gradient sweep, see k_multi_point_grad
     return tiles;
 }
 
@@ -375,24 +374,23 @@ int qd_multi_point_grad_f32(const QdDiffQuantDesc* table, int ntensors, int64_t 
     if (!table || ntensors <= 0 || total_blocks <= 0 || bucket <= 0 || (bucket & (bucket - 1)) || k < 1 || k > kMaxK ||
         !grad_points)
         return QD_ERR_INVALID_ARGUMENT;
-    // total_blocks is what qd_multi_dq_plan wrote: ntensors x (4 B + 1) partial rows
-    const int64_t B = (total_blocks / ntensors - 1) / 4;
-    if (total_blocks != (4 * B + 1) * ntensors || B < 1 || B > 512) return QD_ERR_INVALID_ARGUMENT;
+    // total_blocks is what qd_multi_dq_plan wrote: between 1 and 2048 + 1 partial rows per tensor
+    if (total_blocks < ntensors || total_blocks > (kGradWaves + 1) * (int64_t)ntensors) return QD_ERR_INVALID_ARGUMENT;
     if (!workspace || (((uintptr_t)workspace) & 15) || workspace_bytes < (size_t)total_blocks * k * sizeof(float))
         return QD_ERR_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
     int row_shift = 0;
     while (((int64_t)1 << row_shift) < bucket) ++row_shift;
     float* part = (float*)workspace;
-    // grid: the B blocks of the sweep over the full tiles + one wave per tensor for what is left after them
-    // (a model without a single full tile has B = 1 and T = 0: that block returns at once)
-    const unsigned grid = (unsigned)(B + (ntensors + 3) / 4);
+    // grid: the 512 blocks of the sweep over the full tiles (a wave beyond the last tile returns at once) + one wave per
+    // tensor for what is left after them
+    const unsigned grid = (unsigned)(kGradBlocks + (ntensors + 3) / 4);
     if (k <= 4)
-        hipLaunchKernelGGL((k_multi_point_grad<4>), dim3(grid), dim3(256), 0, st, table, ntensors, (int)B, bucket, row_shift, k, part);
+        hipLaunchKernelGGL((k_multi_point_grad<4>), dim3(grid), dim3(256), 0, st, table, ntensors, bucket, row_shift, k, part);
     else
-        hipLaunchKernelGGL((k_multi_point_grad<0>), dim3(grid), dim3(256), (size_t)k * 256 * sizeof(float), st, table, ntensors, (int)B,
+        hipLaunchKernelGGL((k_multi_point_grad<0>), dim3(grid), dim3(256), (size_t)k * 256 * sizeof(float), st, table, ntensors,
                            bucket, row_shift, k, part);
-    hipLaunchKernelGGL(k_multi_point_grad_final, dim3((unsigned)(ntensors * k)), dim3(256), 0, st, table, ntensors, 4 * B, k, part,
+    hipLaunchKernelGGL(k_multi_point_grad_final, dim3((unsigned)(ntensors * k)), dim3(256), 0, st, table, ntensors, k, part,
                        grad_points);
     return (int)hipGetLastError();
 }

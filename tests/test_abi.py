@@ -89,14 +89,16 @@ def test_multi_plan_host(lib):
 
 def test_multi_dq_plan_host_and_the_partial_row_layout(lib):
     """qd_multi_dq_plan: first_tile = prefix of 4-bucket forward tiles, first_block = prefix of FULL 1024-element gradient
-    tiles, total_blocks = ntensors x (W + 1) partial rows with W = 4 B waves, B = min(512, ceil(T / 4)).  And the layout claim
-    the backward kernels rest on (csrc/qd_multi_dq.hip): wave g takes full tiles g, g + W, ...; the fold of tensor ti (c full
-    tiles from f0 on) reads rows (f0 + i) mod W, i < min(c, W) -- exactly the waves that had a tile of it, each once -- plus
-    row W iff n mod 1024 (the extra wave's).  Modelled here in Python on the config shape lists and on adversarial ones (empty
-    tensors, tensors below one tile, a single huge tensor)."""
+    tiles, first_row = prefix of partial rows with min(full tiles, W) + 1 rows per tensor, W = 2048 waves; total_blocks = their
+    sum.  And the layout claim the backward kernels rest on (csrc/qd_multi_dq.hip): wave g takes full tiles g, g + W, ...; the
+    waves that visit tensor ti (c full tiles from f0 on) are (f0 + i) mod W, i < min(c, W), each once, and wave g writes row
+    first_row + ((g - f0) mod W) -- so the rows of a tensor are exactly 0 .. min(c, W) - 1, written once each, plus row
+    min(c, W) for the extra wave (n mod 1024).  Modelled here in Python on the config shape lists and on adversarial ones
+    (empty tensors, tensors below one tile, a single huge tensor, 200 small tensors: ADVICE r05's 105 MB case)."""
     import ctypes
     import numpy as np
     from harness import kernel_bench
+    W = 2048
 
     def plan(ns, bucket=256):
         T = (_lib.QdDiffQuantDesc * len(ns))()
@@ -104,25 +106,28 @@ def test_multi_dq_plan_host_and_the_partial_row_layout(lib):
             T[i].n = n
         blocks = ctypes.c_int64(0)
         tiles = lib.qd_multi_dq_plan(T, len(ns), bucket, ctypes.byref(blocks))
-        return tiles, blocks.value, [T[i].first_tile for i in range(len(ns))], [T[i].first_block for i in range(len(ns))]
+        return (tiles, blocks.value, [T[i].first_tile for i in range(len(ns))], [T[i].first_block for i in range(len(ns))],
+                [T[i].first_row for i in range(len(ns))])
 
-    tiles, rows, ft, fb = plan([800000, 10, 0, 1025, 5000])
+    tiles, rows, ft, fb, fr = plan([800000, 10, 0, 1025, 5000])
     assert ft == [0, 782, 783, 783, 785] and tiles == 790
     assert fb == [0, 781, 781, 781, 782]                      # n // 1024: 781, 0, 0, 1, 4
-    assert rows == 5 * (4 * min(512, -(-786 // 4)) + 1)
-    assert plan([0, 0])[1] == 2 * (4 * 1 + 1)                    # nothing to do: one block, which returns at once
+    assert fr == [0, 782, 783, 784, 786] and rows == 791       # 781 + 1, 1, 1, 1 + 1, 4 + 1
+    assert plan([0, 0])[1] == 2                                # nothing to do: one (never read) row each
+    assert plan([1 << 26])[1] == W + 1                         # 65536 full tiles: every wave visits it
+    small = [int(x) for x in np.random.RandomState(1).randint(1, 70000, 200)]
+    assert plan(small)[1] == sum(n // 1024 + 1 for n in small) < 200 * 70            # (round 5: 200 x 2049 rows)
 
     rng = np.random.RandomState(0)
     cases = [[int(np.prod(s)) for s in kernel_bench.model_shapes('wrn')], [int(np.prod(s)) for s in kernel_bench.model_shapes('student')],
              [1 << 26], [1, 1, 1, 1, 1, 1, 1, 1, 1], [0, 5, 0, 0, 7000, 0, 3, 0], [1024] * 40 + [0] + [1025] * 3,
              [int(x) for x in rng.randint(0, 300000, 200)], [int(x) for x in rng.randint(1, 3000, 64)], [3 << 20, 0, 1, 5 << 20]]
     for ns in cases:
-        _tiles, rows, _ft, fb = plan(ns)
+        _tiles, rows, _ft, fb, fr = plan(ns)
         nt = len(ns)
         T = fb[-1] + ns[-1] // 1024
-        assert T == sum(n // 1024 for n in ns) and rows % nt == 0 and (rows // nt - 1) % 4 == 0
-        W = rows // nt - 1
-        assert 4 <= W <= 2048 and W == 4 * max(1, min(512, -(-T // 4)))
+        assert T == sum(n // 1024 for n in ns)
+        assert fr == list(np.cumsum([0] + [min(n // 1024, W) + 1 for n in ns[:-1]])) and rows == fr[-1] + min(ns[-1] // 1024, W) + 1
         tiles_t = np.arange(T)
         owner = np.searchsorted(np.asarray(fb + [T]), tiles_t, side='right') - 1         # last tensor with prefix <= t ...
         wave = tiles_t % W
@@ -132,8 +137,8 @@ def test_multi_dq_plan_host_and_the_partial_row_layout(lib):
             if c == 0:                                            # ... which never is a tensor without a full tile
                 assert not touched
                 continue
-            read = [(fb[ti] + i) % W for i in range(min(c, W))]
-            assert len(set(read)) == len(read) and sorted(read) == touched
+            written = sorted((g - fb[ti]) % W for g in touched)   # the row (relative to first_row) each visiting wave writes
+            assert written == list(range(min(c, W)))              # 0 .. min(c, W) - 1, each once: what the fold reads, front to back
 
 
 def test_kernels_are_gfx950_only(lib):
