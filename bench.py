@@ -79,8 +79,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-dp-configs', action='store_true', help='skip the ImageNet-shaped and seq2seq steps/sec legs')
     ap.add_argument('--precondition-s', type=float, default=0.4, help='seconds of untimed back-to-back launches before warm-up')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 child processes (kernel duration + PMC HBM traffic of the headline kernel)')
-    ap.add_argument('--budget-s', type=float, default=100.0,
-                    help='wall budget of the run: an OPTIONAL leg starts only if its expected duration still fits (0: no limit)')
+    ap.add_argument('--budget-s', type=float, default=None,
+                    help='wall budget of the run: an OPTIONAL leg starts only if its expected duration still fits (0: no limit; default: '
+                         '100 s at N = 1, 240 s at N > 1, where the steps/sec legs are what the run is for and rendezvous takes its time)')
     ap.add_argument('--deadline-s', type=float, default=1500.0,
                     help='after this many seconds the guardian ends the worker and prints the line with what has been measured so far')
     ap.add_argument('--skip-legs', default='', help='comma-separated legs to leave out (%s)' % ', '.join(LEGS[1:]))
@@ -203,6 +204,7 @@ def worker_main(args):
         line['rccl_world_size'], line['rccl_error'] = group['world'], group['error']
 
     off = disabled_legs(args, n_gpus)
+    budget_s = args.budget_s if args.budget_s is not None else (100.0 if n_gpus == 1 else 240.0)
     resume = None
     if args.resume:
         with open(args.resume) as f:
@@ -238,11 +240,11 @@ def worker_main(args):
         body through the LegRunner (an exception becomes an 'error' record on every rank), a snapshot afterwards."""
         if not want(name):
             return
-        if name in OPTIONAL and args.budget_s > 0:
+        if name in OPTIONAL and budget_s > 0:
             spent = time.time() - t_start
-            go = runner.rank0_says(spent + OPTIONAL[name] <= args.budget_s or args.quick)
+            go = runner.rank0_says(spent + OPTIONAL[name] <= budget_s or args.quick)
             if not go:
-                store({'skipped': 'wall budget: %.0f s spent + ~%d s expected > --budget-s %.0f' % (spent, OPTIONAL[name], args.budget_s)})
+                store({'skipped': 'wall budget: %.0f s spent + ~%d s expected > --budget-s %.0f' % (spent, OPTIONAL[name], budget_s)})
                 wall[name] = 'budget'
                 done.append(name)
                 return
