@@ -381,7 +381,7 @@ def worker_main(args):
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
         committed = bl.load_pmc_traffic()
         roofline = {
-            'bound': 'hbm', 'kernel': 'k_bucket_vec<MODE_QDQ,16,4>',
+            'bound': 'hbm', 'kernel': 'k_bucket_vec<0,16,4,1>',      # as rocprofv3 names it (mode 0 = quantize-dequantize; profiles/r06_bench_kernel_stats.csv)
             'achieved': round(achieved, 1), 'peak': bl.HBM_PEAK_GBPS, 'unit': 'GB/s',
             'frac': round(achieved / bl.HBM_PEAK_GBPS, 4),
             'traffic': int(round(committed)) if committed else None,
